@@ -1,0 +1,172 @@
+/*
+ * mmada_mi355x.h — C-ABI of libmmada_mi355x.so: the MI355X (gfx950) denoising hot path of the
+ * MMaDA-Parallel parallel text+image sampler.
+ *
+ * The reference (tyfeld/MMaDA-Parallel, 100 % Python) has no FFI layer; the path sits behind two Python call
+ * contracts.  Each entry point below names the reference code it replaces (paths relative to
+ * /root/reference/MMaDA-Parallel-A unless prefixed).  INTEGRATION.md shows the ctypes stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *   - every pointer documented "device" is a device pointer owned by the caller (normally a torch tensor's
+ *     data_ptr()); the library never frees caller memory.  bf16 data are raw uint16 bit patterns.
+ *   - every function returns 0 on success, non-zero on error; mmada_last_error() returns a thread-local message.
+ *   - all work is enqueued on the `stream` argument (a hipStream_t passed as void*); no hidden host syncs
+ *     (mmada_bind_* and mmada_create allocate and are not graph-capturable; the forward / select calls are).
+ *   - one handle per (process, device); a handle is used from one host thread at a time.
+ */
+#ifndef MMADA_MI355X_H
+#define MMADA_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mmada_handle mmada_handle;
+
+/* Model hyper-parameters: read from the checkpoint's config.json by the caller, never hard-coded
+ * (model/configuration_llada.py:129-384 ModelConfig; model/modeling_llada.py:1063-1142 LLaDAModel.__init__). */
+typedef struct mmada_cfg {
+    int32_t d_model;        /* 4096 */
+    int32_t n_layers;       /* 32 */
+    int32_t n_heads;        /* 32 */
+    int32_t n_kv_heads;     /* 32 (== n_heads unless GQA) */
+    int32_t head_dim;       /* must be 128 */
+    int32_t mlp_hidden;     /* 12288 (ff_proj / up_proj out features) */
+    int32_t vocab;          /* embedding_size = rows of wte / lm head (>= 134548) */
+    int32_t max_seq;        /* RoPE table length (max_sequence_length) */
+    float   rms_eps;        /* rms_norm_eps */
+    float   rope_theta;     /* rope_theta */
+    int32_t tp_rank;        /* tensor-parallel rank  (0 when tp_size == 1) */
+    int32_t tp_size;        /* tensor-parallel degree (1, 2, 4, 8) */
+    int32_t mask_token_id;  /* 126336 (inference.py:22-31) */
+    int32_t text_vocab_size;/* 126356 = image-token offset (inference.py:87-89) */
+    int32_t codebook_size;  /* 8192 */
+    int32_t reserved;
+} mmada_cfg;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------------- */
+
+/* Replaces LLaDAModel.__init__ (model/modeling_llada.py:1063-1142) incl. the RotaryEmbedding cache warm-up
+ * (:363-400).  `inv_freq_host` (64 floats, host) may be NULL: then inv_freq[i] = theta^(-2i/128) is computed by
+ * the library; pass the torch-computed vector to reproduce the reference's fp32 table bit-for-bit. */
+int mmada_create(const mmada_cfg* cfg, const float* inv_freq_host, mmada_handle** out);
+int mmada_destroy(mmada_handle* h);
+const char* mmada_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int mmada_abi_version(void);
+
+/* ---- weights (state-dict keys of SURVEY.md §5.4; model/modeling_llada.py:1097-1131, 864-893, 564-575) ---------- */
+
+/* model.transformer.wte.weight [vocab,d], model.transformer.ln_f.weight [d], model.transformer.ff_out.weight
+ * [vocab,d]; bf16 device pointers, BORROWED (must outlive the handle). */
+int mmada_bind_globals(mmada_handle* h, const void* wte, const void* ln_f, const void* lm_head);
+
+/* model.transformer.blocks.{layer}.*: all nine tensors in checkpoint layout (nn.Linear [out,in], bf16, device,
+ * UNSHARDED).  The library repacks them into its own MI355X layout (fused+RoPE-permuted QKV, 16-column
+ * interleaved gate/up, TP slices by cfg.tp_rank) on `stream`; the caller may free the originals once the
+ * stream has drained. */
+int mmada_bind_layer(mmada_handle* h, int layer,
+                     const void* attn_norm, const void* ff_norm,
+                     const void* q_proj, const void* k_proj, const void* v_proj, const void* attn_out,
+                     const void* ff_proj, const void* up_proj, const void* ff_out,
+                     void* stream);
+
+/* ---- workspace ---------------------------------------------------------------------------------------------- */
+
+/* Bytes of activation workspace needed for a forward of B sequences of length L (all equal length: the
+ * reference never masks padding). */
+size_t mmada_workspace_bytes(const mmada_handle* h, int B, int L);
+/* Caller-owned device buffer (>= mmada_workspace_bytes for the largest (B,L) used), 256-byte aligned. */
+int mmada_set_workspace(mmada_handle* h, void* ws, size_t bytes);
+
+/* ---- transformer forward -------------------------------------------------------------------------------------
+ * Replaces LLaDAForMultiModalGeneration.forward(infer=True) → LLaDAModelLM.forward → LLaDAModel.forward
+ * (model/modeling_xllmx_dimoo.py:41-72, model/modeling_llada.py:1462-1511, 1201-1415) without the dead
+ * attention-bias plumbing. */
+
+/* Embedding + all n_layers blocks; leaves the final residual stream resident in the workspace (tp_size == 1). */
+int mmada_forward_body(mmada_handle* h, const int64_t* ids /*device [B,L]*/, int B, int L, void* stream);
+
+/* ln_f + LM head on a row subset (model/modeling_llada.py:1392,1399-1404):
+ * logits_out[r, :] = ff_out.weight[col_begin:col_end] · ln_f(x[rows[r]]) ; rows[r] = b*L + l (device int32 [R]);
+ * logits_out bf16 device [R, col_end-col_begin].  Covers the reference's slices
+ * cond_logits[:, text_start:text_end, :] and [:, pos, 126356:134548] (generators/parallel_generator.py:185,236-239,267-274). */
+int mmada_head_rows(mmada_handle* h, const int32_t* rows, int R, int col_begin, int col_end,
+                    void* logits_out, void* stream);
+
+/* Drop-in full forward: logits_out bf16 device [B, L, vocab] (generators/parallel_generator.py:178,263,264). */
+int mmada_forward(mmada_handle* h, const int64_t* ids, int B, int L, void* logits_out, void* stream);
+
+/* Segment entry points for tensor parallelism (the caller interleaves the RCCL all-reduce of the partial
+ * buffer returned by mmada_partial_ptr between them):
+ *   mmada_embed → for each layer { mmada_attn_partial, [all-reduce], mmada_mlp_partial, [all-reduce] }.
+ * *_partial writes  (rank==0 ? x : 0) + local partial of the row-parallel GEMM  into the partial buffer and makes
+ * it the new residual stream; summing it over ranks yields the reference's x + attn_out(...) / x + ff_out(...). */
+int mmada_embed(mmada_handle* h, const int64_t* ids, int B, int L, void* stream);
+int mmada_attn_partial(mmada_handle* h, int layer, void* stream);
+int mmada_mlp_partial(mmada_handle* h, int layer, void* stream);
+/* Device pointer / byte size of the current residual-stream buffer ([B*Lp, d_model] bf16, Lp = L rounded up to 8). */
+void* mmada_stream_ptr(mmada_handle* h);
+size_t mmada_stream_bytes(const mmada_handle* h);
+
+/* Debug / parity taps: copy the residual stream rows [b*L+l] (pad rows dropped) to out bf16 [B*L, d]. */
+int mmada_read_stream(mmada_handle* h, void* out, void* stream);
+
+/* ---- sampler math (generators/parallel_generator.py) ---------------------------------------------------------- */
+
+/* Text step, generators/parallel_generator.py:181-217 (low_confidence remasking):
+ *   x0 = argmax(logits [+ gumbel]) (first index on ties); p = softmax(float64(logits)); conf = masked ? p[x0] : -inf;
+ *   the k[b] highest-confidence masked positions of row b get ids[b, text_start + t] = x0.
+ * logits: bf16 device [B,T,ld_logits] (row stride ld_logits elements, V columns used).
+ * noisy:  NULL (text_temperature == 0) or bf16 device [B,T,ld_logits] = add_gumbel_noise(logits) (:8-20) — argmax
+ *         is taken over it, confidence over `logits`.
+ * k:      device int32 [B] (num_transfer_tokens[:, step], :78-99).   ids: device int64 [B,L], updated in place.
+ * scratch: device, >= B*T*16 bytes. */
+int mmada_text_select(mmada_handle* h, const void* logits, const void* noisy, int B, int T, int V, int ld_logits,
+                      int64_t* ids, int L, int text_start, const int32_t* k, void* scratch, void* stream);
+
+/* Image step part 1, generators/parallel_generator.py:282-295,311: dual-CFG combine with the reference's per-op
+ * bf16 rounding, softmax → bf16 probabilities, first-index argmax, probability of the argmax.
+ * cond/unc_text/unc_img: bf16 device [B,N,CB] (unc_* may be NULL when the matching scale == 0).
+ * probs_out: NULL or bf16 device [B,N,CB] (needed only for temperature > 0, torch.multinomial :297-302).
+ * argmax_out: device int32 [B,N];  pmax_out: bf16 device [B,N]. */
+int mmada_image_probs(mmada_handle* h, const void* cond, const void* unc_text, const void* unc_img,
+                      int B, int N, int CB, float cfg_scale, float cfg_img,
+                      void* probs_out, int32_t* argmax_out, void* pmax_out, void* stream);
+
+/* Image step part 2, generators/parallel_generator.py:221-233,304-344 + mask_by_random_topk :23-70:
+ *   vq = ids[b, pos_map[n]] (MASK → unknown); sampled = unknown ? sampled_in : clamp(vq - text_vocab);
+ *   conf = log(bf16(unknown ? p_in : bf16_max) + 1e-10) [+ temp·noise] (bf16 arithmetic);
+ *   mask_len = clamp(max(1, min(unknown_count-1, *mask_len_sched)), 0, N-1); the mask_len lowest-confidence
+ *   positions (stable order) are re-masked, all others get ids = sampled + text_vocab.
+ * sampled_in: device int32 [B,N]; p_in: bf16 device [B,N]; noise: NULL or bf16 device [B,N] (randn, :30-33);
+ * mask_len_sched: device int32 [1] = floor(N·cos(ratio·π/2)) for this step (:318-321). */
+int mmada_image_commit(mmada_handle* h, int64_t* ids, int B, int L, const int32_t* pos_map, int N,
+                       const int32_t* sampled_in, const void* p_in, const void* noise, float remask_temp,
+                       const int32_t* mask_len_sched, void* stream);
+
+/* (M variant) LFQ codebook gather, MMaDA-Parallel-M/models/modeling_magvitv2.py:186-194,208-221:
+ * out[b, c, n] = 2·bit_c(idx[b,n]) − 1 as bf16/f32, c in [0,nbits) with bit 0 = most significant
+ * (mask = 2^(nbits-1-c)).  idx: device int64 [B,N]; out: device [B,nbits,N] (dtype_f32 ? float : bf16). */
+int mmada_lfq_gather(mmada_handle* h, const int64_t* idx, int B, int N, int nbits, int dtype_f32, void* out,
+                     void* stream);
+
+/* ---- low-level kernels exposed for parity tests and profiling -------------------------------------------------- */
+
+/* C[M,N] = A[M,K] · W[N,K]^T, bf16 in / fp32 accumulate / bf16 out (F.linear without bias). */
+int mmada_gemm_bt(const void* A, const void* W, void* C, int M, int N, int K, void* stream);
+/* RMSLayerNorm.forward (model/modeling_llada.py:301-329): out = w * bf16(x * rsqrt(mean(x²)+eps)). */
+int mmada_rmsnorm(const void* x, const void* w, void* out, int rows, int d, float eps, void* stream);
+/* Unmasked non-causal SDPA over [B,H,L,128] q/k/v (bf16, contiguous) → out [B,L,H*128]
+ * (model/modeling_llada.py:643-679,731-744). Uses the handle's workspace for the K-major V copy. */
+int mmada_sdpa(mmada_handle* h, const void* q, const void* k, const void* v, void* out, int B, int H, int Hkv, int L,
+               void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MMADA_MI355X_H */

@@ -1,0 +1,9 @@
+"""mmada_parallel_amd — MI355X-native hot path of the MMaDA-Parallel parallel text+image sampler.
+
+Public surface mirrors the reference (tyfeld/MMaDA-Parallel, MMaDA-Parallel-A):
+    from mmada_parallel_amd import LLaDAForMultiModalGeneration, generate_ti2ti
+"""
+from .model import LLaDAForMultiModalGeneration, LLaDAConfigLite  # noqa: F401
+from .generators.parallel_generator import generate_ti2ti, cosine_schedule  # noqa: F401
+
+__all__ = ["LLaDAForMultiModalGeneration", "LLaDAConfigLite", "generate_ti2ti", "cosine_schedule"]

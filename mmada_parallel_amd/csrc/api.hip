@@ -1,0 +1,378 @@
+// api.hip — the C-ABI of include/mmada_mi355x.h: handle, weight repack, workspace carving and the launch sequence
+// of one denoiser forward (embedding → n_layers × [RMSNorm → QKV+RoPE GEMM → flash attention → attn_out GEMM +
+// residual → RMSNorm → gate/up GEMM + SiLU·mul → down GEMM + residual] → RMSNorm → LM-head rows).
+// Host code only; every kernel lives in gemm.hip / attention.hip / elementwise.hip / sampler.hip.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <cmath>
+#include <utility>
+#include <vector>
+
+#include "../../include/mmada_mi355x.h"
+#include "kernels.h"
+
+static thread_local char g_err[1024] = "";
+
+int mm_fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+struct LayerWeights {
+    bf16_t* wqkv = nullptr;   // [(Hq_l + 2 Hkv_l) * 128, d]   fused, rotary-partner permuted
+    bf16_t* wo = nullptr;     // [d, Hq_l * 128]
+    bf16_t* wgu = nullptr;    // [2 F_l, d]                    16-row interleaved ff_proj / up_proj
+    bf16_t* wdown = nullptr;  // [d, F_l]
+    bf16_t* attn_norm = nullptr;  // [d]
+    bf16_t* ff_norm = nullptr;    // [d]
+    bool bound = false;
+};
+
+struct mmada_handle {
+    mmada_cfg cfg;
+    int hq_l, hkv_l, f_l;  // per-rank heads / mlp columns
+    float* rope_cos = nullptr;
+    float* rope_sin = nullptr;
+    const bf16_t* wte = nullptr;
+    const bf16_t* ln_f = nullptr;
+    const bf16_t* lm_head = nullptr;
+    std::vector<LayerWeights> layers;
+    // workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    // current carve
+    int B = 0, L = 0, Lp = 0, Lkv = 0, M = 0;
+    bf16_t *x = nullptr, *y = nullptr, *xn = nullptr, *att = nullptr, *hbuf = nullptr, *q = nullptr, *k = nullptr,
+           *vT = nullptr, *xg = nullptr;
+    int32_t* rows_all = nullptr;
+};
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int ceil_to(int v, int a) { return (v + a - 1) / a * a; }
+
+struct Carve {
+    size_t x, y, xn, att, h, q, k, vT, xg, rows, total;
+    int Lp, Lkv, M;
+};
+
+static Carve carve_for(const mmada_handle* h, int B, int L) {
+    Carve c;
+    const int d = h->cfg.d_model;
+    c.Lp = ceil_to(L, 8);
+    c.Lkv = ceil_to(L, 64);
+    c.M = B * c.Lp;
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        size_t o = off;
+        off = align_up(off + bytes, 256);
+        return o;
+    };
+    c.x = take((size_t)c.M * d * 2);
+    c.y = take((size_t)c.M * d * 2);
+    c.xn = take((size_t)c.M * d * 2);
+    c.att = take((size_t)c.M * h->hq_l * 128 * 2);
+    c.h = take((size_t)c.M * h->f_l * 2);
+    c.q = take((size_t)B * h->hq_l * c.Lkv * 128 * 2);
+    c.k = take((size_t)B * h->hkv_l * c.Lkv * 128 * 2);
+    c.vT = take((size_t)B * h->hkv_l * 128 * c.Lkv * 2);
+    c.xg = take((size_t)B * L * d * 2);
+    c.rows = take((size_t)B * L * 4);
+    c.total = off;
+    return c;
+}
+
+extern "C" {
+
+int mmada_abi_version(void) { return 1; }
+const char* mmada_last_error(void) { return g_err; }
+
+int mmada_create(const mmada_cfg* cfg, const float* inv_freq_host, mmada_handle** out) {
+    if (!cfg || !out) return mm_fail("mmada_create: null argument");
+    if (cfg->head_dim != 128) return mm_fail("mmada_create: head_dim must be 128 (got %d)", cfg->head_dim);
+    if (cfg->d_model != cfg->n_heads * cfg->head_dim) return mm_fail("mmada_create: d_model != n_heads*head_dim");
+    if (cfg->n_kv_heads <= 0 || cfg->n_heads % cfg->n_kv_heads) return mm_fail("mmada_create: bad n_kv_heads");
+    if (cfg->tp_size < 1 || cfg->tp_rank < 0 || cfg->tp_rank >= cfg->tp_size) return mm_fail("mmada_create: bad tp rank/size");
+    if (cfg->n_kv_heads % cfg->tp_size || cfg->n_heads % cfg->tp_size) return mm_fail("mmada_create: heads not divisible by tp_size");
+    if (cfg->mlp_hidden % (64 * cfg->tp_size)) return mm_fail("mmada_create: mlp_hidden must be a multiple of 64*tp_size");
+    if (cfg->d_model % 64) return mm_fail("mmada_create: d_model must be a multiple of 64");
+    if (cfg->max_seq <= 0 || cfg->n_layers <= 0 || cfg->vocab <= 0) return mm_fail("mmada_create: bad sizes");
+    mmada_handle* h = new mmada_handle();
+    h->cfg = *cfg;
+    h->hq_l = cfg->n_heads / cfg->tp_size;
+    h->hkv_l = cfg->n_kv_heads / cfg->tp_size;
+    h->f_l = cfg->mlp_hidden / cfg->tp_size;
+    h->layers.resize(cfg->n_layers);
+    // RoPE tables (model/modeling_llada.py:391-397)
+    float inv[64];
+    for (int i = 0; i < 64; ++i)
+        inv[i] = inv_freq_host ? inv_freq_host[i] : (float)(1.0 / pow((double)cfg->rope_theta, (double)(2 * i) / 128.0));
+    float* inv_dev = nullptr;
+    MM_CHECK_HIP(hipMalloc(&inv_dev, sizeof(inv)));
+    MM_CHECK_HIP(hipMemcpy(inv_dev, inv, sizeof(inv), hipMemcpyHostToDevice));
+    MM_CHECK_HIP(hipMalloc(&h->rope_cos, (size_t)cfg->max_seq * 64 * 4));
+    MM_CHECK_HIP(hipMalloc(&h->rope_sin, (size_t)cfg->max_seq * 64 * 4));
+    if (launch_rope_table(h->rope_cos, h->rope_sin, inv_dev, cfg->max_seq, 0)) return 1;
+    MM_CHECK_HIP(hipDeviceSynchronize());
+    MM_CHECK_HIP(hipFree(inv_dev));
+    *out = h;
+    return 0;
+}
+
+int mmada_destroy(mmada_handle* h) {
+    if (!h) return 0;
+    for (auto& lw : h->layers) {
+        hipFree(lw.wqkv); hipFree(lw.wo); hipFree(lw.wgu); hipFree(lw.wdown); hipFree(lw.attn_norm); hipFree(lw.ff_norm);
+    }
+    hipFree(h->rope_cos);
+    hipFree(h->rope_sin);
+    delete h;
+    return 0;
+}
+
+int mmada_bind_globals(mmada_handle* h, const void* wte, const void* ln_f, const void* lm_head) {
+    if (!h || !wte || !ln_f || !lm_head) return mm_fail("mmada_bind_globals: null argument");
+    h->wte = (const bf16_t*)wte;
+    h->ln_f = (const bf16_t*)ln_f;
+    h->lm_head = (const bf16_t*)lm_head;
+    return 0;
+}
+
+int mmada_bind_layer(mmada_handle* h, int layer, const void* attn_norm, const void* ff_norm, const void* q_proj,
+                     const void* k_proj, const void* v_proj, const void* attn_out, const void* ff_proj,
+                     const void* up_proj, const void* ff_out, void* stream) {
+    if (!h) return mm_fail("mmada_bind_layer: null handle");
+    if (layer < 0 || layer >= h->cfg.n_layers) return mm_fail("mmada_bind_layer: layer %d out of range", layer);
+    if (!attn_norm || !ff_norm || !q_proj || !k_proj || !v_proj || !attn_out || !ff_proj || !up_proj || !ff_out)
+        return mm_fail("mmada_bind_layer: null weight pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const mmada_cfg& c = h->cfg;
+    const int d = c.d_model;
+    LayerWeights& lw = h->layers[layer];
+    const size_t nqkv = (size_t)(h->hq_l + 2 * h->hkv_l) * 128;
+    if (!lw.wqkv) {
+        MM_CHECK_HIP(hipMalloc(&lw.wqkv, nqkv * d * 2));
+        MM_CHECK_HIP(hipMalloc(&lw.wo, (size_t)d * h->hq_l * 128 * 2));
+        MM_CHECK_HIP(hipMalloc(&lw.wgu, (size_t)2 * h->f_l * d * 2));
+        MM_CHECK_HIP(hipMalloc(&lw.wdown, (size_t)d * h->f_l * 2));
+        MM_CHECK_HIP(hipMalloc(&lw.attn_norm, (size_t)d * 2));
+        MM_CHECK_HIP(hipMalloc(&lw.ff_norm, (size_t)d * 2));
+    }
+    if (launch_pack_qkv((const bf16_t*)q_proj, (const bf16_t*)k_proj, (const bf16_t*)v_proj, lw.wqkv, d, c.n_heads,
+                        c.n_kv_heads, c.tp_rank, c.tp_size, s)) return 1;
+    if (launch_pack_cols((const bf16_t*)attn_out, lw.wo, d, c.n_heads * 128, c.tp_rank, c.tp_size, s)) return 1;
+    if (launch_pack_gate_up((const bf16_t*)ff_proj, (const bf16_t*)up_proj, lw.wgu, d, c.mlp_hidden, c.tp_rank,
+                            c.tp_size, s)) return 1;
+    if (launch_pack_cols((const bf16_t*)ff_out, lw.wdown, d, c.mlp_hidden, c.tp_rank, c.tp_size, s)) return 1;
+    MM_CHECK_HIP(hipMemcpyAsync(lw.attn_norm, attn_norm, (size_t)d * 2, hipMemcpyDeviceToDevice, s));
+    MM_CHECK_HIP(hipMemcpyAsync(lw.ff_norm, ff_norm, (size_t)d * 2, hipMemcpyDeviceToDevice, s));
+    lw.bound = true;
+    return 0;
+}
+
+size_t mmada_workspace_bytes(const mmada_handle* h, int B, int L) {
+    if (!h || B <= 0 || L <= 0) return 0;
+    return carve_for(h, B, L).total;
+}
+
+int mmada_set_workspace(mmada_handle* h, void* ws, size_t bytes) {
+    if (!h || !ws) return mm_fail("mmada_set_workspace: null argument");
+    if (((uintptr_t)ws) & 255) return mm_fail("mmada_set_workspace: workspace must be 256-byte aligned");
+    h->ws = (char*)ws;
+    h->ws_bytes = bytes;
+    h->B = h->L = 0;
+    return 0;
+}
+
+static int apply_carve(mmada_handle* h, int B, int L, hipStream_t s) {
+    if (B <= 0 || L <= 0) return mm_fail("forward: bad shape B=%d L=%d", B, L);
+    if (L > h->cfg.max_seq) return mm_fail("forward: L=%d exceeds max_seq=%d", L, h->cfg.max_seq);
+    const Carve c = carve_for(h, B, L);
+    if (!h->ws || c.total > h->ws_bytes)
+        return mm_fail("forward: workspace too small (%zu needed, %zu set)", c.total, h->ws_bytes);
+    h->B = B; h->L = L; h->Lp = c.Lp; h->Lkv = c.Lkv; h->M = c.M;
+    h->x = (bf16_t*)(h->ws + c.x); h->y = (bf16_t*)(h->ws + c.y); h->xn = (bf16_t*)(h->ws + c.xn);
+    h->att = (bf16_t*)(h->ws + c.att); h->hbuf = (bf16_t*)(h->ws + c.h); h->q = (bf16_t*)(h->ws + c.q);
+    h->k = (bf16_t*)(h->ws + c.k); h->vT = (bf16_t*)(h->ws + c.vT); h->xg = (bf16_t*)(h->ws + c.xg);
+    h->rows_all = (int32_t*)(h->ws + c.rows);
+    // vT columns [Lp, Lkv) are never written by the QKV epilogue but are multiplied by P == 0: keep them finite
+    if (c.Lkv > c.Lp)
+        MM_CHECK_HIP(hipMemset2DAsync(h->vT + c.Lp, (size_t)c.Lkv * 2, 0, (size_t)(c.Lkv - c.Lp) * 2,
+                                      (size_t)B * h->hkv_l * 128, s));
+    return 0;
+}
+
+static int check_bound(const mmada_handle* h) {
+    if (!h->wte) return mm_fail("forward: mmada_bind_globals was not called");
+    for (int i = 0; i < h->cfg.n_layers; ++i)
+        if (!h->layers[i].bound) return mm_fail("forward: layer %d not bound", i);
+    return 0;
+}
+
+int mmada_embed(mmada_handle* h, const int64_t* ids, int B, int L, void* stream) {
+    if (!h || !ids) return mm_fail("mmada_embed: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (check_bound(h)) return 1;
+    if (apply_carve(h, B, L, s)) return 1;
+    return launch_embed(ids, h->wte, h->x, B, L, h->Lp, h->cfg.d_model, h->cfg.vocab, s);
+}
+
+int mmada_attn_partial(mmada_handle* h, int layer, void* stream) {
+    if (!h || h->M == 0) return mm_fail("mmada_attn_partial: call mmada_embed first");
+    if (layer < 0 || layer >= h->cfg.n_layers) return mm_fail("mmada_attn_partial: bad layer");
+    hipStream_t s = (hipStream_t)stream;
+    const LayerWeights& lw = h->layers[layer];
+    const int d = h->cfg.d_model;
+    if (launch_rmsnorm(h->x, lw.attn_norm, h->xn, h->M, d, h->cfg.rms_eps, s)) return 1;
+    GemmArgs g{};
+    g.A = h->xn; g.W = lw.wqkv; g.C = nullptr;
+    g.M = h->M; g.N = (h->hq_l + 2 * h->hkv_l) * 128; g.K = d;
+    g.lda = d; g.ldw = d; g.ldc = 0;
+    g.q = h->q; g.k = h->k; g.vT = h->vT; g.rope_cos = h->rope_cos; g.rope_sin = h->rope_sin;
+    g.Lp = h->Lp; g.Lkv = h->Lkv; g.Hq = h->hq_l; g.Hkv = h->hkv_l;
+    if (launch_gemm(EPI_QKV, g, s)) return 1;
+    if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->Lp, h->Lkv, h->Lp, h->hq_l * 128, s))
+        return 1;
+    GemmArgs o{};
+    o.A = h->att; o.W = lw.wo; o.C = h->y;
+    o.M = h->M; o.N = d; o.K = h->hq_l * 128;
+    o.lda = o.K; o.ldw = o.K; o.ldc = d;
+    o.resid = h->x; o.ldr = d; o.add_resid = (h->cfg.tp_rank == 0);
+    if (launch_gemm(EPI_RESID, o, s)) return 1;
+    std::swap(h->x, h->y);
+    return 0;
+}
+
+int mmada_mlp_partial(mmada_handle* h, int layer, void* stream) {
+    if (!h || h->M == 0) return mm_fail("mmada_mlp_partial: call mmada_embed first");
+    if (layer < 0 || layer >= h->cfg.n_layers) return mm_fail("mmada_mlp_partial: bad layer");
+    hipStream_t s = (hipStream_t)stream;
+    const LayerWeights& lw = h->layers[layer];
+    const int d = h->cfg.d_model;
+    if (launch_rmsnorm(h->x, lw.ff_norm, h->xn, h->M, d, h->cfg.rms_eps, s)) return 1;
+    GemmArgs g{};
+    g.A = h->xn; g.W = lw.wgu; g.C = h->hbuf;
+    g.M = h->M; g.N = 2 * h->f_l; g.K = d;
+    g.lda = d; g.ldw = d; g.ldc = h->f_l;
+    if (launch_gemm(EPI_SWIGLU, g, s)) return 1;
+    GemmArgs o{};
+    o.A = h->hbuf; o.W = lw.wdown; o.C = h->y;
+    o.M = h->M; o.N = d; o.K = h->f_l;
+    o.lda = h->f_l; o.ldw = h->f_l; o.ldc = d;
+    o.resid = h->x; o.ldr = d; o.add_resid = (h->cfg.tp_rank == 0);
+    if (launch_gemm(EPI_RESID, o, s)) return 1;
+    std::swap(h->x, h->y);
+    return 0;
+}
+
+void* mmada_stream_ptr(mmada_handle* h) { return h ? (void*)h->x : nullptr; }
+size_t mmada_stream_bytes(const mmada_handle* h) { return h ? (size_t)h->M * h->cfg.d_model * 2 : 0; }
+
+int mmada_forward_body(mmada_handle* h, const int64_t* ids, int B, int L, void* stream) {
+    if (!h) return mm_fail("mmada_forward_body: null handle");
+    if (h->cfg.tp_size != 1)
+        return mm_fail("mmada_forward_body: tp_size=%d needs the segment API (mmada_embed/attn_partial/mlp_partial)",
+                       h->cfg.tp_size);
+    if (mmada_embed(h, ids, B, L, stream)) return 1;
+    for (int i = 0; i < h->cfg.n_layers; ++i) {
+        if (mmada_attn_partial(h, i, stream)) return 1;
+        if (mmada_mlp_partial(h, i, stream)) return 1;
+    }
+    return 0;
+}
+
+int mmada_head_rows(mmada_handle* h, const int32_t* rows, int R, int col_begin, int col_end, void* logits_out,
+                    void* stream) {
+    if (!h || h->M == 0) return mm_fail("mmada_head_rows: no forward resident");
+    if (!rows || !logits_out) return mm_fail("mmada_head_rows: null argument");
+    if (R <= 0) return 0;
+    if (R > h->B * h->L) return mm_fail("mmada_head_rows: R=%d exceeds B*L=%d", R, h->B * h->L);
+    if (col_begin < 0 || col_end > h->cfg.vocab || col_begin >= col_end) return mm_fail("mmada_head_rows: bad column range");
+    hipStream_t s = (hipStream_t)stream;
+    const int d = h->cfg.d_model;
+    if (launch_rmsnorm_gather(h->x, h->ln_f, h->xg, rows, R, h->L, h->Lp, d, h->cfg.rms_eps, s)) return 1;
+    GemmArgs g{};
+    g.A = h->xg; g.W = h->lm_head + (size_t)col_begin * d; g.C = (bf16_t*)logits_out;
+    g.M = R; g.N = col_end - col_begin; g.K = d;
+    g.lda = d; g.ldw = d; g.ldc = g.N;
+    return launch_gemm(EPI_STORE, g, s);
+}
+
+int mmada_forward(mmada_handle* h, const int64_t* ids, int B, int L, void* logits_out, void* stream) {
+    if (mmada_forward_body(h, ids, B, L, stream)) return 1;
+    if (launch_iota_rows(h->rows_all, B * L, (hipStream_t)stream)) return 1;
+    return mmada_head_rows(h, h->rows_all, B * L, 0, h->cfg.vocab, logits_out, stream);
+}
+
+int mmada_read_stream(mmada_handle* h, void* out, void* stream) {
+    if (!h || h->M == 0 || !out) return mm_fail("mmada_read_stream: no forward resident");
+    return launch_unpad_rows(h->x, (bf16_t*)out, h->B, h->L, h->Lp, h->cfg.d_model, (hipStream_t)stream);
+}
+
+int mmada_text_select(mmada_handle* h, const void* logits, const void* noisy, int B, int T, int V, int ld_logits,
+                      int64_t* ids, int L, int text_start, const int32_t* k, void* scratch, void* stream) {
+    if (!h || !logits || !ids || !k || !scratch) return mm_fail("mmada_text_select: null argument");
+    if (text_start < 0 || text_start + T > L) return mm_fail("mmada_text_select: text span outside the sequence");
+    return launch_text_select((const bf16_t*)logits, (const bf16_t*)noisy, B, T, V, ld_logits, ids, L, text_start, k,
+                              scratch, h->cfg.mask_token_id, (hipStream_t)stream);
+}
+
+int mmada_image_probs(mmada_handle* h, const void* cond, const void* unc_text, const void* unc_img, int B, int N, int CB,
+                      float cfg_scale, float cfg_img, void* probs_out, int32_t* argmax_out, void* pmax_out,
+                      void* stream) {
+    if (!h || !cond || !argmax_out || !pmax_out) return mm_fail("mmada_image_probs: null argument");
+    return launch_image_probs((const bf16_t*)cond, (const bf16_t*)unc_text, (const bf16_t*)unc_img, B, N, CB, cfg_scale,
+                              cfg_img, (bf16_t*)probs_out, argmax_out, (bf16_t*)pmax_out, (hipStream_t)stream);
+}
+
+int mmada_image_commit(mmada_handle* h, int64_t* ids, int B, int L, const int32_t* pos_map, int N,
+                       const int32_t* sampled_in, const void* p_in, const void* noise, float remask_temp,
+                       const int32_t* mask_len_sched, void* stream) {
+    if (!h || !ids || !pos_map || !sampled_in || !p_in || !mask_len_sched) return mm_fail("mmada_image_commit: null argument");
+    return launch_image_commit(ids, B, L, pos_map, N, sampled_in, (const bf16_t*)p_in, (const bf16_t*)noise, remask_temp,
+                               mask_len_sched, h->cfg.mask_token_id, h->cfg.text_vocab_size, h->cfg.codebook_size,
+                               (hipStream_t)stream);
+}
+
+int mmada_lfq_gather(mmada_handle* h, const int64_t* idx, int B, int N, int nbits, int dtype_f32, void* out,
+                     void* stream) {
+    (void)h;
+    if (!idx || !out) return mm_fail("mmada_lfq_gather: null argument");
+    if (nbits <= 0 || nbits > 62) return mm_fail("mmada_lfq_gather: bad nbits");
+    return launch_lfq_gather(idx, out, B, N, nbits, dtype_f32, (hipStream_t)stream);
+}
+
+int mmada_gemm_bt(const void* A, const void* W, void* C, int M, int N, int K, void* stream) {
+    if (!A || !W || !C) return mm_fail("mmada_gemm_bt: null argument");
+    GemmArgs g{};
+    g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.C = (bf16_t*)C;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N;
+    return launch_gemm(EPI_STORE, g, (hipStream_t)stream);
+}
+
+int mmada_rmsnorm(const void* x, const void* w, void* out, int rows, int d, float eps, void* stream) {
+    if (!x || !w || !out) return mm_fail("mmada_rmsnorm: null argument");
+    return launch_rmsnorm((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out, rows, d, eps, (hipStream_t)stream);
+}
+
+int mmada_sdpa(mmada_handle* h, const void* q, const void* k, const void* v, void* out, int B, int H, int Hkv, int L,
+               void* stream) {
+    if (!h || !q || !k || !v || !out) return mm_fail("mmada_sdpa: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const int Lkv = ceil_to(L, 64);
+    const size_t qb = align_up((size_t)B * H * Lkv * 128 * 2, 256), kb = align_up((size_t)B * Hkv * Lkv * 128 * 2, 256);
+    if (!h->ws || qb + 2 * kb > h->ws_bytes) return mm_fail("mmada_sdpa: workspace too small (%zu needed)", qb + 2 * kb);
+    bf16_t* qp = (bf16_t*)h->ws;
+    bf16_t* kp = (bf16_t*)(h->ws + qb);
+    bf16_t* vt = (bf16_t*)(h->ws + qb + kb);
+    h->M = 0;  // the resident forward (if any) is clobbered
+    if (launch_pad_heads((const bf16_t*)q, qp, B * H, L, Lkv, s)) return 1;
+    if (launch_pad_heads((const bf16_t*)k, kp, B * Hkv, L, Lkv, s)) return 1;
+    if (launch_transpose_v((const bf16_t*)v, vt, B * Hkv, L, Lkv, s)) return 1;
+    return launch_attention(qp, kp, vt, (bf16_t*)out, B, H, Hkv, L, L, Lkv, L, H * 128, s);
+}
+
+}  // extern "C"

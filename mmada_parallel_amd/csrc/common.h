@@ -1,0 +1,60 @@
+// common.h — shared device helpers for the gfx950 kernels (bf16 bit handling, wave64 reductions).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define MM_DEVICE __device__ __forceinline__
+
+// bf16 <-> f32, round-to-nearest-even (what torch's .to(bfloat16) does).  NaN kept quiet.
+MM_DEVICE float bf2f(bf16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+MM_DEVICE bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+// round an f32 to the nearest bf16 value, returned as f32
+MM_DEVICE float bfround(float f) { return bf2f(f2bf(f)); }
+MM_DEVICE uint32_t pack_bf2(float lo, float hi) { return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16); }
+
+// wave64 butterfly reductions
+MM_DEVICE float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+MM_DEVICE double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+MM_DEVICE float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware, bijective remap of a linear workgroup id: consecutive hardware ids round-robin over the 8 XCDs
+// (observed, speed only), so give each XCD a contiguous chunk of the logical tile sequence.
+MM_DEVICE int xcd_remap(int bid, int nwg) {
+    const int NX = 8;
+    int xcd = bid % NX, idx = bid / NX;
+    int q = nwg / NX, r = nwg % NX;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+#define MM_CHECK_HIP(expr)                                                                 \
+    do {                                                                                   \
+        hipError_t _e = (expr);                                                            \
+        if (_e != hipSuccess) return mm_fail("%s:%d %s: %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+int mm_fail(const char* fmt, ...);

@@ -1,0 +1,61 @@
+// kernels.h — host-side launcher declarations shared between the .hip translation units and api.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "common.h"
+
+enum GemmEpilogue { EPI_STORE = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_QKV = 3 };
+
+struct GemmArgs {
+    const bf16_t* A;   // [M, lda]   activations, K-contiguous
+    const bf16_t* W;   // [N, ldw]   nn.Linear weight layout (out, in), K-contiguous
+    bf16_t* C;         // [M, ldc]   (EPI_STORE / EPI_RESID / EPI_SWIGLU: ldc = N/2)
+    int M, N, K;
+    int lda, ldw, ldc;
+    // EPI_RESID: C = bf16(resid + bf16(acc)) when add_resid, else bf16(acc)
+    const bf16_t* resid;
+    int ldr;
+    int add_resid;
+    // EPI_QKV: rows are (b, l) with m = b*Lp + l; columns are [q heads | k heads | v heads] x 128
+    bf16_t* q;         // [B, Hq , Lkv, 128]
+    bf16_t* k;         // [B, Hkv, Lkv, 128]
+    bf16_t* vT;        // [B, Hkv, 128, Lkv]
+    const float* rope_cos;  // [max_seq, 64]
+    const float* rope_sin;  // [max_seq, 64]
+    int Lp, Lkv, Hq, Hkv;
+};
+
+int launch_gemm(int epi, const GemmArgs& g, hipStream_t s);
+
+// elementwise.hip
+int launch_embed(const int64_t* ids, const bf16_t* wte, bf16_t* x, int B, int L, int Lp, int d, int vocab, hipStream_t s);
+int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int d, float eps, hipStream_t s);
+// gathered rmsnorm: out[r] = rmsnorm(x[map(rows[r])]) where rows[r] = b*L + l and x rows are b*Lp + l
+int launch_rmsnorm_gather(const bf16_t* x, const bf16_t* w, bf16_t* out, const int32_t* rows, int R, int L, int Lp,
+                          int d, float eps, hipStream_t s);
+int launch_rope_table(float* cos_t, float* sin_t, const float* inv_freq_dev, int max_seq, hipStream_t s);
+int launch_unpad_rows(const bf16_t* x, bf16_t* out, int B, int L, int Lp, int d, hipStream_t s);
+int launch_iota_rows(int32_t* rows, int n, hipStream_t s);
+// weight repack
+int launch_pack_qkv(const bf16_t* wq, const bf16_t* wk, const bf16_t* wv, bf16_t* out, int d, int Hq, int Hkv, int tp_rank,
+                    int tp_size, hipStream_t s);
+int launch_pack_gate_up(const bf16_t* gate, const bf16_t* up, bf16_t* out, int d, int F, int tp_rank, int tp_size,
+                        hipStream_t s);
+int launch_pack_cols(const bf16_t* w, bf16_t* out, int rows, int cols, int tp_rank, int tp_size, hipStream_t s);
+// [B,H,L,128] -> padded q/k layout or K-major V copy (for the standalone mmada_sdpa entry point)
+int launch_pad_heads(const bf16_t* in, bf16_t* out, int BH, int L, int Lkv, hipStream_t s);
+int launch_transpose_v(const bf16_t* v, bf16_t* vT, int BH, int L, int Lkv, hipStream_t s);
+int launch_lfq_gather(const int64_t* idx, void* out, int B, int N, int nbits, int f32, hipStream_t s);
+
+// attention.hip:  q [B,Hq,Lkv,128], k [B,Hkv,Lkv,128], vT [B,Hkv,128,Lkv] -> out rows (b*Lp_out + l) x (Hq*128)
+int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int B, int Hq, int Hkv, int L,
+                     int Lq_rows, int Lkv, int out_row_stride_per_batch, int ld_out, hipStream_t s);
+
+// sampler.hip
+int launch_text_select(const bf16_t* logits, const bf16_t* noisy, int B, int T, int V, int ld, int64_t* ids, int L,
+                       int text_start, const int32_t* k, void* scratch, int mask_id, hipStream_t s);
+int launch_image_probs(const bf16_t* cond, const bf16_t* ut, const bf16_t* ui, int B, int N, int CB, float cfg_scale,
+                       float cfg_img, bf16_t* probs_out, int32_t* argmax_out, bf16_t* pmax_out, hipStream_t s);
+int launch_image_commit(int64_t* ids, int B, int L, const int32_t* pos_map, int N, const int32_t* sampled_in,
+                        const bf16_t* p_in, const bf16_t* noise, float remask_temp, const int32_t* mask_len_sched,
+                        int mask_id, int text_vocab, int codebook, hipStream_t s);

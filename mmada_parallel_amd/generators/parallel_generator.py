@@ -1,0 +1,232 @@
+"""MI355X-native `generate_ti2ti`: same signature and results as the reference sampler
+(generators/parallel_generator.py:102-368), with the tensor math on HIP kernels and no host sync inside the loop.
+
+Control flow (step schedule, which forwards run, CFG prefix overwrite, final read-out incl. the one random fill) is
+the reference's, line for line in meaning; what changed is *where* the math runs:
+  * model forward            -> libmmada_mi355x (mmada_forward_body), LM head only on the rows/columns consumed
+  * text argmax/softmax/topk -> mmada_text_select        (reference :181-217)
+  * VQ gather + CFG + softmax + argmax -> mmada_head_rows + mmada_image_probs   (:236-295)
+  * keep-known / confidence / re-mask / write-back -> mmada_image_commit        (:221-233, :304-344, :23-70)
+All per-step counts (text k, image mask_len) are schedule-determined and precomputed on the host.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from .. import abi
+from ..model import LLaDAForMultiModalGeneration
+
+MASK_TOKEN = 126336
+NEW_LINE = 126084
+
+
+def cosine_schedule(t):
+    """Cosine noise schedule (reference :73-75; inference.py:37-38)."""
+    return torch.cos(t * math.pi / 2)
+
+
+def get_num_transfer_tokens(text_masked_indices: torch.Tensor, text_steps: int) -> torch.Tensor:
+    """Tokens to unmask per step (reference :78-99): remaining - int(total * (1 - (s+1)/S)), Python float math."""
+    batch_size = text_masked_indices.shape[0]
+    initial_masks = text_masked_indices.sum(dim=1).tolist()
+    num_transfer = torch.zeros(batch_size, text_steps, dtype=torch.long)
+    for b in range(batch_size):
+        total = int(initial_masks[b])
+        remaining = total
+        for step in range(text_steps):
+            ratio = (step + 1) / text_steps
+            target_remaining = int(total * (1 - ratio))
+            n = max(0, remaining - target_remaining)
+            num_transfer[b, step] = n
+            remaining -= n
+    return num_transfer
+
+
+def image_step_indices(text_steps: int, timesteps: int) -> List[int]:
+    """Steps at which an image denoising step runs (reference :157-159); duplicates collapse via `in`."""
+    return torch.linspace(text_steps // 4, text_steps - 1, timesteps).round().int().tolist()
+
+
+def mask_len_schedule(num_vq_tokens: int, text_steps: int, noise_schedule=cosine_schedule) -> List[int]:
+    """floor(N * noise_schedule(ratio)) per step as int (reference :318-321); fp32 on the host like the CPU oracle.
+
+    Note cos(pi/2) is -4.37e-8 in fp32, so the last step yields -1."""
+    out = []
+    for step in range(text_steps):
+        ratio = 1.0 * (step + 1) / text_steps
+        mask_ratio = noise_schedule(torch.tensor(ratio))
+        out.append(int((num_vq_tokens * mask_ratio).floor().long().item()))
+    return out
+
+
+def add_gumbel_noise(logits, temperature=1.0, generator=None):
+    """Reference :8-20 verbatim in meaning (bf16 noise, torch RNG) — torch-ROCm plumbing for text_temperature > 0."""
+    if temperature == 0:
+        return logits
+    if generator is not None:
+        u = torch.rand(logits.shape, dtype=logits.dtype, device=logits.device, generator=generator)
+    else:
+        u = torch.rand_like(logits)
+    g = -torch.log(-torch.log(u + 1e-10) + 1e-10)
+    return logits + temperature * g
+
+
+@torch.no_grad()
+def generate_ti2ti(
+    model,
+    input_ids,
+    text_start,
+    text_end,
+    image_start,
+    seq_len,
+    newline_every,
+    text_steps=100,
+    text_gen_length=256,
+    text_block_length=64,
+    timesteps=100,
+    temperature=1.0,
+    text_temperature=0.7,
+    cfg_scale=0.0,
+    cfg_img=4.0,
+    uncon_text=None,
+    uncon_image=None,
+    tokenizer=None,
+    remasking='low_confidence',
+    noise_schedule=cosine_schedule,
+    generator=None,
+    text_vocab_size=126356,
+    codebook_size=8192,
+    return_state=False,
+):
+    """Joint text+image generation; returns (List[int] vq ids, str | List[int] text) like the reference.
+
+    `return_state=True` additionally returns the final `combined_input_ids` *before* the random fill of
+    still-masked image tokens (reference :360-362) — the quantity parity tests compare."""
+    if not isinstance(model, LLaDAForMultiModalGeneration):
+        raise TypeError("generate_ti2ti (MI355X) needs mmada_parallel_amd.LLaDAForMultiModalGeneration; "
+                        "there is no PyTorch fallback path")
+    if remasking != 'low_confidence':
+        raise NotImplementedError(remasking)  # 'random' is broken in the reference with a generator
+    lib, h = model._lib, model._handle
+    device = model.device
+    ids = input_ids.to(device=device, dtype=torch.long).clone().contiguous()
+    B, L = ids.shape
+    V = model.vocab
+
+    num_vq_tokens = seq_len
+    total_image_len = seq_len + seq_len // newline_every
+    image_end = image_start + total_image_len
+    T = text_end - text_start
+
+    # ---- host-side schedules (one D2H copy at setup, none inside the loop) ----
+    ids_host = ids.cpu()
+    text_masked0 = ids_host[:, text_start:text_end] == MASK_TOKEN
+    num_transfer = get_num_transfer_tokens(text_masked0, text_steps)  # [B, steps]
+    remaining_text = text_masked0.sum(dim=1)  # [B]
+    img_steps = set(image_step_indices(text_steps, timesteps))
+    pos_list = [i for i in range(image_start, image_end) if ids_host[0, i] != NEW_LINE]
+    assert len(pos_list) == num_vq_tokens, f"Expected {num_vq_tokens} VQ tokens, got {len(pos_list)}"
+    mlen = mask_len_schedule(num_vq_tokens, text_steps, noise_schedule)
+
+    k_dev = num_transfer.t().contiguous().to(device=device, dtype=torch.int32)  # [steps, B]
+    mlen_dev = torch.tensor(mlen, dtype=torch.int32, device=device)
+    pos_map = torch.tensor(pos_list, dtype=torch.int32, device=device)
+    N = num_vq_tokens
+    brow = torch.arange(B, dtype=torch.int32, device=device)[:, None] * L
+    text_rows = (brow + torch.arange(text_start, text_end, dtype=torch.int32, device=device)[None, :]).reshape(-1)
+    img_rows_1 = (brow + pos_map[None, :]).reshape(-1)                                     # cond batch  [B*N]
+    brow2 = torch.arange(2 * B, dtype=torch.int32, device=device)[:, None] * L
+    img_rows_2 = (brow2 + pos_map[None, :]).reshape(-1)                                    # uncond batch [2B*N]
+    scratch = torch.empty(B * T * 16, dtype=torch.uint8, device=device)
+    argmax = torch.empty((B, N), dtype=torch.int32, device=device)
+    pmax = torch.empty((B, N), dtype=torch.bfloat16, device=device)
+
+    want_ut = cfg_scale > 0.0 and uncon_text is not None
+    want_ui = cfg_img > 0.0 and uncon_image is not None
+    need_uncond = want_ut or want_ui
+    if uncon_text is not None:
+        uncon_text = uncon_text.to(device=device, dtype=torch.long)
+    if uncon_image is not None:
+        uncon_image = uncon_image.to(device=device, dtype=torch.long)
+
+    masked_left = remaining_text.clone()
+    for step in range(text_steps):
+        # ===== forward: conditional logits (reference :177-178), only the rows/columns that are consumed =====
+        model.forward_body(ids)
+        st = abi.stream_ptr()
+        is_img = step in img_steps
+        cond_vq = model.head_rows(img_rows_1, text_vocab_size, text_vocab_size + codebook_size) if is_img else None
+
+        # ===== text step (reference :181-217) =====
+        if int(masked_left.sum()) > 0:
+            text_logits = model.head_rows(text_rows, 0, V)  # [B*T, V]
+            noisy = None
+            if text_temperature != 0:
+                noisy = add_gumbel_noise(text_logits.view(B, T, V), temperature=text_temperature,
+                                         generator=generator).contiguous()
+            abi.check(lib.mmada_text_select(h, text_logits.data_ptr(), abi.ptr(noisy), B, T, V, V, ids.data_ptr(), L,
+                                            text_start, k_dev[step].data_ptr(), scratch.data_ptr(), st),
+                      "mmada_text_select")
+            masked_left = masked_left - num_transfer[:, step]
+
+        # ===== image step (reference :220-344) =====
+        if is_img:
+            ut = ui = None
+            if need_uncond:
+                # unconditional sequences: prefix overwritten in place, same length (reference :250-259, A.3)
+                unc = ids.repeat(2, 1)
+                if uncon_text is not None:
+                    unc[:B, :uncon_text.shape[1]] = uncon_text
+                if uncon_image is not None:
+                    unc[B:, :uncon_image.shape[1]] = uncon_image
+                model.forward_body(unc)  # both uncond forwards run whenever either scale > 0 (reference :243)
+                unc_vq = model.head_rows(img_rows_2, text_vocab_size, text_vocab_size + codebook_size)
+                ut, ui = unc_vq[:B * N], unc_vq[B * N:]
+            elif cfg_scale != 0.0 or cfg_img != 0.0:
+                # reference :275-278: uncond logits are zeros when no uncond input exists
+                ut = ui = torch.zeros_like(cond_vq)
+            probs = None
+            if temperature != 0:
+                probs = torch.empty((B * N, codebook_size), dtype=torch.bfloat16, device=device)
+            abi.check(lib.mmada_image_probs(h, cond_vq.data_ptr(), abi.ptr(ut), abi.ptr(ui), B, N, codebook_size,
+                                            float(cfg_scale), float(cfg_img), abi.ptr(probs), argmax.data_ptr(),
+                                            pmax.data_ptr(), st), "mmada_image_probs")
+            if temperature == 0:
+                sampled, p_sel = argmax, pmax
+            else:
+                if generator is not None:
+                    s64 = torch.multinomial(probs, 1, generator=generator)
+                else:
+                    s64 = torch.multinomial(probs, 1)
+                p_sel = torch.gather(probs, -1, s64).view(B, N).contiguous()
+                sampled = s64.view(B, N).to(torch.int32).contiguous()
+            ratio = 1.0 * (step + 1) / text_steps
+            img_temp = temperature * (1.0 - ratio)
+            # randn is drawn even at temperature 0 (reference :30-33, A.2) so the RNG stream advances identically
+            if generator is not None:
+                noise = torch.randn((B, N), dtype=torch.bfloat16, device=device, generator=generator)
+            else:
+                noise = torch.randn((B, N), dtype=torch.bfloat16, device=device)
+            abi.check(lib.mmada_image_commit(h, ids.data_ptr(), B, L, pos_map.data_ptr(), N, sampled.data_ptr(),
+                                             p_sel.data_ptr(), noise.data_ptr(), float(img_temp),
+                                             mlen_dev[step:step + 1].data_ptr(), st), "mmada_image_commit")
+
+    # ===== final read-out (reference :346-368) =====
+    final_ids = ids.cpu()
+    text_tokens = [t for t in final_ids[0, text_start:text_end].tolist() if t != MASK_TOKEN]
+    generated_text = tokenizer.decode(text_tokens, skip_special_tokens=True) if tokenizer is not None else text_tokens
+    image_tokens = []
+    for pos in pos_list:
+        token = int(final_ids[0, pos])
+        if token != MASK_TOKEN:
+            image_tokens.append(max(0, min(token - text_vocab_size, codebook_size - 1)))
+        else:
+            # still masked -> sample randomly from the global CPU RNG, exactly like the reference (A.1)
+            image_tokens.append(int(torch.randint(0, codebook_size, (1,)).item()))
+    if return_state:
+        return image_tokens, generated_text, final_ids
+    return image_tokens, generated_text

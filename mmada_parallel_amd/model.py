@@ -1,0 +1,228 @@
+"""Host-side mirror of the reference model contract, backed by libmmada_mi355x.so.
+
+`LLaDAForMultiModalGeneration` keeps the surface `generate_ti2ti` / `inference.py` use:
+    model = LLaDAForMultiModalGeneration.from_pretrained(path, torch_dtype=torch.bfloat16, device_map="auto")
+    model(ids, infer=True, use_cache=False).logits        # [B, L, V] bf16
+    model.config.text_vocab_size / codebook_size ; model.device
+(reference: model/modeling_xllmx_dimoo.py:24-72, model/modeling_llada.py:1462-1511, inference.py:83-89).
+
+Extra fast-path methods (`forward_body`, `head_rows`) let the accelerated sampler avoid materialising [L, V] logits.
+PyTorch is used for device memory, streams and (TP) torch.distributed only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+from types import SimpleNamespace
+from typing import Dict, Optional
+
+import torch
+
+from . import abi
+
+_SUPPORTED = dict(block_type="llama", activation_type="silu", layer_norm_type="rms")
+
+
+class CausalLMOutputLite(SimpleNamespace):
+    """Minimal stand-in for transformers' CausalLMOutputWithPast: only `.logits` is consumed on this path."""
+
+
+class LLaDAConfigLite(SimpleNamespace):
+    def get(self, k, default=None):
+        return getattr(self, k, default)
+
+
+def _validate(cfg: LLaDAConfigLite) -> None:
+    def _name(v):
+        return getattr(v, "value", v)
+
+    for k, want in _SUPPORTED.items():
+        got = _name(cfg.get(k, want))
+        if got is not None and str(got) != want:
+            raise NotImplementedError(f"config.{k}={got!r}: only {want!r} is on the MI355X hot path")
+    for flag in ("alibi", "attention_layer_norm", "scale_logits", "input_emb_norm", "include_bias", "include_qkv_bias"):
+        if cfg.get(flag, False):
+            raise NotImplementedError(f"config.{flag}=True is not supported on the MI355X hot path")
+    if not cfg.get("rope", True) or not cfg.get("rope_full_precision", True):
+        raise NotImplementedError("rope=True and rope_full_precision=True are required")
+    if cfg.d_model // cfg.n_heads != 128:
+        raise NotImplementedError("head_dim must be 128")
+
+
+class LLaDAForMultiModalGeneration:
+    """MI355X-native drop-in for the reference class of the same name (inference path only)."""
+
+    MASK_TOKEN = 126336
+
+    def __init__(self, config, state_dict: Dict[str, torch.Tensor], device: Optional[torch.device] = None,
+                 tp_rank: int = 0, tp_size: int = 1, max_batch: int = 3, max_seq: Optional[int] = None):
+        if isinstance(config, dict):
+            config = LLaDAConfigLite(**config)
+        _validate(config)
+        if not torch.cuda.is_available():
+            raise abi.MmadaError("LLaDAForMultiModalGeneration needs an MI355X (torch.cuda unavailable); "
+                                 "there is no CPU fallback")
+        self.config = config
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.dtype = torch.bfloat16
+        self.tp_rank, self.tp_size = tp_rank, tp_size
+        self._lib = abi.lib()
+        self._handle = C.c_void_p()
+        self._ws = None
+        self._ws_shape = (0, 0)
+        self.n_kv_heads = config.get("n_kv_heads") or config.n_heads
+        self.vocab = config.get("embedding_size") or config.vocab_size
+        self.mlp_hidden = config.get("mlp_hidden_size") or config.get("mlp_ratio", 4) * config.d_model
+        self.max_seq = max_seq or config.get("max_sequence_length", 4096)
+        self.max_batch = max_batch
+
+        c = abi.MmadaCfg(
+            d_model=config.d_model, n_layers=config.n_layers, n_heads=config.n_heads, n_kv_heads=self.n_kv_heads,
+            head_dim=128, mlp_hidden=self.mlp_hidden, vocab=self.vocab, max_seq=self.max_seq,
+            rms_eps=float(config.get("rms_norm_eps", 1e-5)), rope_theta=float(config.get("rope_theta", 10000.0)),
+            tp_rank=tp_rank, tp_size=tp_size, mask_token_id=int(config.get("mask_token_id", self.MASK_TOKEN)),
+            text_vocab_size=int(config.get("text_vocab_size", 126356)),
+            codebook_size=int(config.get("codebook_size", 8192)), reserved=0)
+        # inv_freq exactly as RotaryEmbedding.get_rotary_embedding computes it (model/modeling_llada.py:391-393)
+        inv_freq = 1.0 / (c.rope_theta ** (torch.arange(0, 128, 2, dtype=torch.float) / 128))
+        inv = (C.c_float * 64)(*inv_freq.tolist())
+        with torch.cuda.device(self.device):
+            abi.check(self._lib.mmada_create(C.byref(c), inv, C.byref(self._handle)), "mmada_create")
+            self._bind(state_dict)
+
+    # ---- loading ------------------------------------------------------------------------------------------------
+    def _bind(self, sd: Dict[str, torch.Tensor]) -> None:
+        p = "model.transformer."
+        dev, dt = self.device, torch.bfloat16
+
+        def get(name):
+            if name not in sd:
+                raise KeyError(f"checkpoint is missing {name}")
+            return sd[name].to(device=dev, dtype=dt).contiguous()
+
+        self._wte = get(p + "wte.weight")
+        self._ln_f = get(p + "ln_f.weight")
+        self._head = self._wte if self.config.get("weight_tying", False) else get(p + "ff_out.weight")
+        abi.check(self._lib.mmada_bind_globals(self._handle, self._wte.data_ptr(), self._ln_f.data_ptr(),
+                                               self._head.data_ptr()), "mmada_bind_globals")
+        st = abi.stream_ptr()
+        for i in range(self.config.n_layers):
+            b = f"{p}blocks.{i}."
+            names = ["attn_norm", "ff_norm", "q_proj", "k_proj", "v_proj", "attn_out", "ff_proj", "up_proj", "ff_out"]
+            ts = [get(b + n + ".weight") for n in names]
+            abi.check(self._lib.mmada_bind_layer(self._handle, i, *[t.data_ptr() for t in ts], st), "mmada_bind_layer")
+            torch.cuda.current_stream().synchronize()  # originals may be freed once the repack has drained
+            del ts
+
+    @classmethod
+    def from_state_dict(cls, config, state_dict, **kw):
+        return cls(config, state_dict, **kw)
+
+    @classmethod
+    def from_pretrained(cls, path: str, torch_dtype=torch.bfloat16, device_map="auto", **kw):
+        """Loads config.json + *.safetensors with the reference's state-dict keys (checkpoints drop in unchanged)."""
+        from safetensors import safe_open
+
+        if torch_dtype not in (None, torch.bfloat16):
+            raise NotImplementedError("the MI355X hot path computes in bf16")
+        with open(os.path.join(path, "config.json")) as f:
+            config = LLaDAConfigLite(**json.load(f))
+        files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
+        if not files:
+            raise FileNotFoundError(f"no *.safetensors under {path}")
+
+        class _Lazy(dict):
+            def __init__(self):
+                super().__init__()
+                self._where = {}
+                for fn in files:
+                    with safe_open(os.path.join(path, fn), "pt") as sf:
+                        for k in sf.keys():
+                            self._where[k] = fn
+
+            def __contains__(self, k):
+                return k in self._where
+
+            def __getitem__(self, k):
+                with safe_open(os.path.join(path, self._where[k]), "pt") as sf:
+                    return sf.get_tensor(k)
+
+        return cls(config, _Lazy(), **kw)
+
+    # ---- workspace ------------------------------------------------------------------------------------------------
+    def _ensure_ws(self, B: int, L: int) -> None:
+        need = self._lib.mmada_workspace_bytes(self._handle, B, L)
+        if self._ws is None or self._ws.numel() < need:
+            grow = max(need, self._lib.mmada_workspace_bytes(self._handle, max(B, self.max_batch), L))
+            self._ws = torch.empty(grow + 256, dtype=torch.uint8, device=self.device)
+            base = (self._ws.data_ptr() + 255) // 256 * 256
+            abi.check(self._lib.mmada_set_workspace(self._handle, base, grow), "mmada_set_workspace")
+
+    # ---- forward ---------------------------------------------------------------------------------------------------
+    def forward_body(self, input_ids: torch.Tensor) -> None:
+        """Embedding + all blocks; the final residual stream stays resident for head_rows()."""
+        ids = input_ids.to(device=self.device, dtype=torch.long).contiguous()
+        B, L = ids.shape
+        self._ensure_ws(B, L)
+        st = abi.stream_ptr()
+        if self.tp_size == 1:
+            abi.check(self._lib.mmada_forward_body(self._handle, ids.data_ptr(), B, L, st), "mmada_forward_body")
+        else:
+            import torch.distributed as dist
+
+            abi.check(self._lib.mmada_embed(self._handle, ids.data_ptr(), B, L, st), "mmada_embed")
+            for i in range(self.config.n_layers):
+                for seg in (self._lib.mmada_attn_partial, self._lib.mmada_mlp_partial):
+                    abi.check(seg(self._handle, i, st), "mmada_*_partial")
+                    dist.all_reduce(self._stream_view())
+        self._shape = (B, L)
+
+    def _stream_view(self) -> torch.Tensor:
+        """Torch view of the library's current residual-stream buffer (inside our workspace tensor)."""
+        p = self._lib.mmada_stream_ptr(self._handle)
+        n = self._lib.mmada_stream_bytes(self._handle)
+        off = p - self._ws.data_ptr()
+        return self._ws[off:off + n].view(torch.bfloat16)
+
+    def head_rows(self, rows: torch.Tensor, col_begin: int, col_end: int) -> torch.Tensor:
+        """logits[r] = lm_head[col_begin:col_end] · ln_f(x[rows[r]]), rows = b*L + l (int32, device)."""
+        rows = rows.to(device=self.device, dtype=torch.int32).contiguous()
+        out = torch.empty((rows.numel(), col_end - col_begin), dtype=torch.bfloat16, device=self.device)
+        abi.check(self._lib.mmada_head_rows(self._handle, rows.data_ptr(), rows.numel(), col_begin, col_end,
+                                            out.data_ptr(), abi.stream_ptr()), "mmada_head_rows")
+        return out
+
+    def hidden_state(self) -> torch.Tensor:
+        """Residual stream after the last block, [B, L, d] (parity tap)."""
+        B, L = self._shape
+        out = torch.empty((B, L, self.config.d_model), dtype=torch.bfloat16, device=self.device)
+        abi.check(self._lib.mmada_read_stream(self._handle, out.data_ptr(), abi.stream_ptr()), "mmada_read_stream")
+        return out
+
+    def forward(self, input_ids=None, labels=None, infer=False, use_cache=False, **_):
+        if not infer or labels is not None:
+            raise NotImplementedError("only forward(infer=True) is on the MI355X hot path (training loss is out of scope)")
+        if use_cache:
+            raise NotImplementedError("use_cache=True (dLLM cache) is not on the TI2TI path")
+        self.forward_body(input_ids)
+        B, L = self._shape
+        rows = torch.arange(B * L, dtype=torch.int32, device=self.device)
+        logits = self.head_rows(rows, 0, self.vocab).view(B, L, self.vocab)
+        return CausalLMOutputLite(logits=logits)
+
+    __call__ = forward
+
+    def eval(self):
+        return self
+
+    def to(self, *_a, **_k):
+        return self
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) and self._handle.value:
+                self._lib.mmada_destroy(self._handle)
+                self._handle = C.c_void_p()
+        except Exception:
+            pass

@@ -1,0 +1,106 @@
+"""Synthetic weights and token jobs at the reference's shapes.
+
+No checkpoint, tokenizer or VQ-VAE is available offline, so parity tests and the benchmark run on seeded random
+weights with the reference's state-dict keys (model/modeling_llada.py:1097-1131, 864-893, 564-575) and on a token
+sequence assembled exactly like inference.py:129-161.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+MASK, NEW_LINE, BOI, EOI, BOA, EOA = 126336, 126084, 126349, 126350, 126354, 126355
+TEXT_VOCAB, CODEBOOK = 126356, 8192
+
+CFG_8B = dict(d_model=4096, n_heads=32, n_kv_heads=32, n_layers=32, mlp_hidden_size=12288, vocab_size=134656,
+              embedding_size=134656, rms_norm_eps=1e-5, rope_theta=500000.0, max_sequence_length=4096)
+CFG_TINY = dict(d_model=256, n_heads=2, n_kv_heads=2, n_layers=2, mlp_hidden_size=512, vocab_size=134656,
+                embedding_size=134656, rms_norm_eps=1e-5, rope_theta=500000.0, max_sequence_length=1024)
+
+
+def full_config(cfg: dict) -> dict:
+    """The keyword set LLaDAConfig needs for this architecture (block llama, silu, rms, rope fp32, no bias)."""
+    out = dict(activation_type="silu", block_type="llama", rope=True, rope_full_precision=True,
+               layer_norm_type="rms", weight_tying=False, include_bias=False, include_qkv_bias=False,
+               attention_dropout=0.0, residual_dropout=0.0, embedding_dropout=0.0, alibi=False,
+               attention_layer_norm=False, scale_logits=False, input_emb_norm=False, flash_attention=False,
+               multi_query_attention=None, block_group_size=1, init_device="cpu",
+               text_vocab_size=TEXT_VOCAB, codebook_size=CODEBOOK, mask_token_id=MASK)
+    out.update(cfg)
+    return out
+
+
+def synthetic_state_dict(cfg: dict, seed: int = 0, device: str = "cpu", dtype=torch.bfloat16,
+                         logit_std: Optional[float] = None) -> Dict[str, torch.Tensor]:
+    """Seeded random weights: linear/embedding N(0, 0.02²), norms 1+N(0, 0.02²), LM head N(0, 1/d)."""
+    d, F, V = cfg["d_model"], cfg["mlp_hidden_size"], cfg.get("embedding_size") or cfg["vocab_size"]
+    hd = d // cfg["n_heads"]
+    kv = (cfg.get("n_kv_heads") or cfg["n_heads"]) * hd
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+
+    def rn(shape, std, mean=0.0):
+        t = torch.randn(shape, generator=g, device=device, dtype=torch.float32) * std + mean
+        return t.to(dtype)
+
+    sd: Dict[str, torch.Tensor] = {}
+    p = "model.transformer."
+    sd[p + "wte.weight"] = rn((V, d), 0.02)
+    for i in range(cfg["n_layers"]):
+        b = f"{p}blocks.{i}."
+        sd[b + "attn_norm.weight"] = rn((d,), 0.02, 1.0)
+        sd[b + "ff_norm.weight"] = rn((d,), 0.02, 1.0)
+        sd[b + "q_proj.weight"] = rn((d, d), 0.02)
+        sd[b + "k_proj.weight"] = rn((kv, d), 0.02)
+        sd[b + "v_proj.weight"] = rn((kv, d), 0.02)
+        sd[b + "attn_out.weight"] = rn((d, d), 0.02)
+        sd[b + "ff_proj.weight"] = rn((F, d), 0.02)
+        sd[b + "up_proj.weight"] = rn((F, d), 0.02)
+        sd[b + "ff_out.weight"] = rn((d, F), 0.02)
+    sd[p + "ln_f.weight"] = rn((d,), 0.02, 1.0)
+    sd[p + "ff_out.weight"] = rn((V, d), logit_std if logit_std is not None else d ** -0.5)
+    return sd
+
+
+def add_break_line(sequence: List[int], H: int, W: int, new_number: int = 0) -> List[int]:
+    """utils/image_utils.py:149-157."""
+    result: List[int] = []
+    for i in range(H):
+        result.extend(sequence[i * W:(i + 1) * W] + [new_number])
+    return result
+
+
+def calculate_vq_params(image_height: int, image_width: int, vae_scale: int = 16):
+    """utils/image_utils.py:95-111."""
+    gh, gw = image_height // vae_scale, image_width // vae_scale
+    return gh * gw, gw, gh, gw
+
+
+def synthetic_job(height: int = 512, width: int = 512, text_gen_length: int = 256, prompt_len: int = 64,
+                  uncond_prompt_len: int = 24, in_height: Optional[int] = None, in_width: Optional[int] = None,
+                  seed: int = 1) -> dict:
+    """Token sequence of one TI2TI job assembled like inference.py:117-161 (random prompt / input-image ids).
+
+    512x512 defaults give L = 64 + 1058 + 2 + 1056 + 1 + 256 + 1 = 2438 (BASELINE config 2); 256x256 with a
+    512x512 input image gives L = 1654 (config 1)."""
+    g = torch.Generator().manual_seed(seed)
+    prompt_ids = torch.randint(0, 126000, (prompt_len,), generator=g).tolist()
+    unc_ids = prompt_ids[:uncond_prompt_len]
+    _, _, ih, iw = calculate_vq_params(in_height or 512, in_width or 512)
+    img_vq = (torch.randint(0, CODEBOOK, (ih * iw,), generator=g) + TEXT_VOCAB).tolist()
+    input_img = [BOI] + add_break_line(img_vq, ih, iw, NEW_LINE) + [EOI]
+    con_prefix = prompt_ids[:-1] + input_img + prompt_ids[-1:]
+    uncon_text = unc_ids[:-1] + input_img + unc_ids[-1:]
+    uncon_image = prompt_ids
+    seq_len, newline_every, gh, gw = calculate_vq_params(height, width)
+    img_mask = add_break_line([MASK] * seq_len, gh, gw, NEW_LINE)
+    pred = [BOA, BOI] + img_mask + [EOI] + [MASK] * text_gen_length + [EOA]
+    image_start = len(con_prefix) + 2
+    image_end = image_start + len(img_mask)
+    text_start = image_end + 1
+    return dict(input_ids=torch.tensor(con_prefix + pred, dtype=torch.long).unsqueeze(0),
+                uncon_text=torch.tensor(uncon_text, dtype=torch.long).unsqueeze(0),
+                uncon_image=torch.tensor(uncon_image, dtype=torch.long).unsqueeze(0),
+                text_start=text_start, text_end=text_start + text_gen_length, image_start=image_start,
+                seq_len=seq_len, newline_every=newline_every)

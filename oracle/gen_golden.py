@@ -1,0 +1,185 @@
+"""Generate tests/golden/*.npz by importing and RUNNING the reference itself (CPU, this container only).
+
+    python oracle/gen_golden.py            # needs /root/reference (read-only); never run on the GPU box
+
+The reference has no tests / golden vectors of its own, so these fixtures — outputs of the
+unmodified reference code on seeded synthetic inputs — are what pins the oracle (tests/test_oracle_golden.py)
+and, through it, the HIP path.  Nothing here is copied from the reference; it is imported via sys.path.
+
+Fixtures
+  forward_tiny.npz   LLaDAForMultiModalGeneration(tiny cfg, synthetic weights, bf16)(ids): hidden states after each
+                     block, logits slices (image rows x codebook columns, text rows x first 4096 columns, per-row
+                     top-8) — model/modeling_xllmx_dimoo.py:41-72 + model/modeling_llada.py:1201-1415
+  sampler_traj.npz   generate_ti2ti driven by a STUB model that returns seeded random bf16 logits: the ids the
+                     sampler passes to every model call + final outputs — generators/parallel_generator.py:102-368
+  e2e_tiny.npz       generate_ti2ti with the real tiny model at temperature 0: ids at every model call + outputs
+  logconf_table.npy  torch.log(p + 1e-10) in bf16 for every non-negative bf16 p (parallel_generator.py:36)
+"""
+from __future__ import annotations
+
+import contextlib
+import io
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference/MMaDA-Parallel-A"
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+from mmada_parallel_amd import synth  # noqa: E402  (pure-python helpers: shapes + seeded inputs)
+
+OUT = os.path.join(REPO, "tests", "golden")
+
+
+def bits(t: torch.Tensor) -> np.ndarray:
+    return t.detach().to(torch.bfloat16).contiguous().view(torch.int16).numpy()
+
+
+def tiny_job():
+    return synth.synthetic_job(height=64, width=64, text_gen_length=16, prompt_len=8, uncond_prompt_len=4,
+                               in_height=64, in_width=64, seed=1)
+
+
+def build_reference_model(cfg: dict, sd: dict):
+    from model import LLaDAForMultiModalGeneration
+    from model.configuration_llada import LLaDAConfig
+
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = LLaDAForMultiModalGeneration(LLaDAConfig(**synth.full_config(cfg)))
+    missing, unexpected = m.load_state_dict(sd, strict=True), None
+    return m.to(torch.bfloat16).eval()
+
+
+class Recorder:
+    """Wraps a model: records the ids of every call (the sampler's observable state)."""
+
+    def __init__(self, fn):
+        self.fn, self.calls = fn, []
+
+    def __call__(self, ids, infer=True, use_cache=False):
+        self.calls.append(ids.clone())
+        return self.fn(ids, len(self.calls))
+
+
+def stub_logits(seed: int, call_idx: int, B: int, L: int, V: int) -> torch.Tensor:
+    g = torch.Generator().manual_seed(seed * 100003 + call_idx)
+    return (torch.randn(B, L, V, generator=g) * 2.0).to(torch.bfloat16)
+
+
+def gen_forward():
+    from model.modeling_llada import LLaDAModel  # noqa: F401  (import check)
+
+    cfg = synth.CFG_TINY
+    sd = synthetic_sd()
+    model = build_reference_model(cfg, sd)
+    job = tiny_job()
+    ids = job["input_ids"]
+    taps = []
+    hooks = [blk.register_forward_hook(lambda _m, _i, o: taps.append(o[0].detach().clone()))
+             for blk in model.model.transformer.blocks]
+    with torch.no_grad():
+        logits = model(ids, infer=True, use_cache=False).logits
+    for h in hooks:
+        h.remove()
+    ts, te = job["text_start"], job["text_end"]
+    pos = [i for i in range(job["image_start"], job["image_start"] + job["seq_len"] + job["seq_len"] // job["newline_every"])
+           if int(ids[0, i]) != synth.NEW_LINE]
+    top = torch.topk(logits[0].float(), 8, dim=-1)
+    np.savez_compressed(
+        os.path.join(OUT, "forward_tiny.npz"),
+        ids=ids.numpy(), hidden=np.stack([bits(t[0]) for t in taps]),
+        img_logits=bits(logits[0, pos, synth.TEXT_VOCAB:synth.TEXT_VOCAB + synth.CODEBOOK]),
+        text_logits_head=bits(logits[0, ts:te, :4096]),
+        top8_val=bits(top.values.to(torch.bfloat16)), top8_idx=top.indices.numpy().astype(np.int32),
+        argmax=logits[0].argmax(-1).numpy().astype(np.int32), pos=np.array(pos, np.int32),
+    )
+    print("forward_tiny: L =", ids.shape[1], "hidden", taps[0].shape, "logits", tuple(logits.shape))
+
+
+_SD = None
+
+
+def synthetic_sd():
+    global _SD
+    if _SD is None:
+        _SD = synth.synthetic_state_dict(synth.CFG_TINY, seed=0)
+    return _SD
+
+
+def run_reference_sampler(model, job, **kw):
+    from generators.parallel_generator import generate_ti2ti
+
+    rec = Recorder(model)
+    torch.manual_seed(1234)  # pins the one torch.randint fill and the randn draws (A.2)
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        vq, text = generate_ti2ti(rec, job["input_ids"], job["text_start"], job["text_end"], job["image_start"],
+                                  job["seq_len"], job["newline_every"], uncon_text=job["uncon_text"],
+                                  uncon_image=job["uncon_image"], tokenizer=None, **kw)
+    return rec.calls, vq, text
+
+
+SAMPLER_CASES = {
+    # name: (V_text, CB, kwargs)
+    "img4": dict(text_steps=8, timesteps=4, temperature=0.0, text_temperature=0.0, cfg_scale=0.0, cfg_img=4.0),
+    "both": dict(text_steps=12, timesteps=6, temperature=0.0, text_temperature=0.0, cfg_scale=2.5, cfg_img=4.0),
+    "odd": dict(text_steps=7, timesteps=5, temperature=0.0, text_temperature=0.0, cfg_scale=2.3, cfg_img=0.0),
+    "nocfg": dict(text_steps=8, timesteps=8, temperature=0.0, text_temperature=0.0, cfg_scale=0.0, cfg_img=0.0),
+}
+STUB_TEXT_VOCAB, STUB_CB = 2048, 512
+
+
+def gen_sampler_traj():
+    job = tiny_job()
+    # remap the job onto a small synthetic vocabulary: only MASK / NEW_LINE identities matter to the sampler
+    L = job["input_ids"].shape[1]
+    V = STUB_TEXT_VOCAB + STUB_CB
+    out = {}
+    for ci, (name, kw) in enumerate(SAMPLER_CASES.items()):
+        seed = 7 + ci
+
+        def fn(ids, call_idx, seed=seed):
+            return SimpleNamespace(logits=stub_logits(seed, call_idx, ids.shape[0], ids.shape[1], V))
+
+        calls, vq, text = run_reference_sampler(fn, job, text_vocab_size=STUB_TEXT_VOCAB, codebook_size=STUB_CB, **kw)
+        out[name + "_calls"] = torch.cat(calls, 0).numpy()
+        out[name + "_vq"] = np.array(vq, np.int64)
+        out[name + "_text"] = np.array(text, np.int64)
+        out[name + "_seed"] = np.array(seed)
+        print(f"sampler_traj[{name}]: {len(calls)} model calls, {len(text)} text tokens")
+    np.savez_compressed(os.path.join(OUT, "sampler_traj.npz"), **out)
+
+
+def gen_e2e():
+    cfg = synth.CFG_TINY
+    model = build_reference_model(cfg, synthetic_sd())
+    job = tiny_job()
+
+    def fn(ids, _idx):
+        with torch.no_grad():
+            return model(ids, infer=True, use_cache=False)
+
+    kw = dict(text_steps=8, timesteps=4, temperature=0.0, text_temperature=0.0, cfg_scale=0.0, cfg_img=4.0)
+    calls, vq, text = run_reference_sampler(fn, job, **kw)
+    np.savez_compressed(os.path.join(OUT, "e2e_tiny.npz"), calls=torch.cat(calls, 0).numpy(), vq=np.array(vq, np.int64),
+                        text=np.array(text, np.int64))
+    print(f"e2e_tiny: {len(calls)} model calls; vq[:8]={vq[:8]}")
+
+
+def gen_tables():
+    b = torch.arange(0, 0x7f80, dtype=torch.int32).to(torch.int16)
+    np.save(os.path.join(OUT, "logconf_table.npy"), torch.log(b.view(torch.bfloat16) + 1e-10).view(torch.int16).numpy())
+
+
+if __name__ == "__main__":
+    if not os.path.isdir(REF):
+        sys.exit("reference not mounted at " + REF)
+    os.makedirs(OUT, exist_ok=True)
+    gen_tables()
+    gen_sampler_traj()
+    gen_forward()
+    gen_e2e()

@@ -1,0 +1,74 @@
+"""CPU ORACLE (test infrastructure only): restatement of the generate_ti2ti loop
+(/root/reference/MMaDA-Parallel-A/generators/parallel_generator.py:102-368) on top of the C sampler oracle.
+
+`model_fn(ids) -> logits [B, L, V] bf16` stands for `model(ids, infer=True, use_cache=False).logits` (:178,263,264).
+Every model call's input ids are appended to `trace` so tests can compare trajectories call by call against the
+fixtures recorded from the reference (tests/golden/sampler_traj.npz, e2e_tiny.npz).
+B == 1 only, like the reference's image branch (:166,224,340).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, List, Optional
+
+import torch
+
+from . import sampler_oracle as so
+
+MASK_TOKEN, NEW_LINE = 126336, 126084
+
+
+def get_num_transfer_tokens(n_masked: int, steps: int) -> List[int]:
+    # :78-99
+    out, remaining = [], n_masked
+    for s in range(steps):
+        target = int(n_masked * (1 - (s + 1) / steps))
+        n = max(0, remaining - target)
+        out.append(n)
+        remaining -= n
+    return out
+
+
+def generate(model_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.Tensor, text_start: int, text_end: int,
+             image_start: int, seq_len: int, newline_every: int, text_steps: int, timesteps: int,
+             cfg_scale: float, cfg_img: float, uncon_text: Optional[torch.Tensor], uncon_image: Optional[torch.Tensor],
+             text_vocab_size: int = 126356, codebook_size: int = 8192, trace: Optional[list] = None) -> torch.Tensor:
+    """temperature = text_temperature = 0 path.  Returns the final ids before the random fill (:360-362)."""
+    ids = input_ids.clone()
+    assert ids.shape[0] == 1
+    image_end = image_start + seq_len + seq_len // newline_every
+    n_text_masked = int((ids[0, text_start:text_end] == MASK_TOKEN).sum())
+    k_sched = get_num_transfer_tokens(n_text_masked, text_steps)
+    img_steps = torch.linspace(text_steps // 4, text_steps - 1, timesteps).round().int().tolist()  # :157-159
+    pos = [i for i in range(image_start, image_end) if int(ids[0, i]) != NEW_LINE]  # :164-169
+    assert len(pos) == seq_len
+    lo, hi = text_vocab_size, text_vocab_size + codebook_size
+
+    def call(x):
+        if trace is not None:
+            trace.append(x.clone())
+        return model_fn(x)
+
+    for step in range(text_steps):
+        cond = call(ids)  # :177-178
+        if int((ids[0, text_start:text_end] == MASK_TOKEN).sum()) > 0:  # :183
+            ids, _, _ = so.text_select(cond[:, text_start:text_end, :], None, ids, text_start, [k_sched[step]])
+        if step in img_steps:  # :220
+            cond_vq = cond[:, pos, lo:hi]
+            ut = ui = None
+            if (cfg_scale > 0.0 and uncon_text is not None) or (cfg_img > 0.0 and uncon_image is not None):  # :243
+                a, b = ids.clone(), ids.clone()
+                if uncon_text is not None:
+                    a[:, :uncon_text.shape[1]] = uncon_text
+                if uncon_image is not None:
+                    b[:, :uncon_image.shape[1]] = uncon_image
+                ut, ui = call(a)[:, pos, lo:hi], call(b)[:, pos, lo:hi]
+            else:
+                ut = ui = torch.zeros_like(cond_vq)
+            am, pm, _ = so.image_probs(cond_vq.contiguous(), ut.contiguous(), ui.contiguous(), cfg_scale, cfg_img)
+            ratio = 1.0 * (step + 1) / text_steps
+            mask_ratio = torch.cos(torch.tensor(ratio) * math.pi / 2)  # cosine_schedule :73-75
+            mlen = int((seq_len * mask_ratio).floor().long())  # :321
+            noise = torch.zeros((1, seq_len), dtype=torch.bfloat16)  # temperature 0: 0 * randn
+            ids = so.image_commit(ids, pos, am, pm, noise, 0.0, mlen, MASK_TOKEN, text_vocab_size, codebook_size)
+    return ids

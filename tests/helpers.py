@@ -1,0 +1,48 @@
+"""Shared test helpers (seeded inputs identical to oracle/gen_golden.py)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from mmada_parallel_amd import synth  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+STUB_TEXT_VOCAB, STUB_CB = 2048, 512
+SAMPLER_CASES = {
+    "img4": dict(text_steps=8, timesteps=4, cfg_scale=0.0, cfg_img=4.0),
+    "both": dict(text_steps=12, timesteps=6, cfg_scale=2.5, cfg_img=4.0),
+    "odd": dict(text_steps=7, timesteps=5, cfg_scale=2.3, cfg_img=0.0),
+    "nocfg": dict(text_steps=8, timesteps=8, cfg_scale=0.0, cfg_img=0.0),
+}
+
+
+def tiny_job():
+    return synth.synthetic_job(height=64, width=64, text_gen_length=16, prompt_len=8, uncond_prompt_len=4,
+                               in_height=64, in_width=64, seed=1)
+
+
+def stub_logits(seed, call_idx, B, L, V):
+    g = torch.Generator().manual_seed(seed * 100003 + call_idx)
+    return (torch.randn(B, L, V, generator=g) * 2.0).to(torch.bfloat16)
+
+
+def from_bits(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).view(torch.bfloat16)
+
+
+def bits(t):
+    return t.detach().to("cpu", torch.bfloat16).contiguous().view(torch.int16)
+
+
+_SD = {}
+
+
+def tiny_sd():
+    if "tiny" not in _SD:
+        _SD["tiny"] = synth.synthetic_state_dict(synth.CFG_TINY, seed=0)
+    return _SD["tiny"]

@@ -1,0 +1,146 @@
+"""Pin the CPU oracle against fixtures produced by RUNNING the reference (oracle/gen_golden.py -> tests/golden/)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import GOLDEN, SAMPLER_CASES, STUB_CB, STUB_TEXT_VOCAB, bits, from_bits, stub_logits, tiny_job, tiny_sd
+from mmada_parallel_amd import synth
+from oracle import generate_oracle, llada_oracle
+from oracle import sampler_oracle as so
+
+
+def test_log_conf_table_matches_reference_exhaustively():
+    # torch.log(p + 1e-10) in bf16 for every non-negative bf16 p (parallel_generator.py:36)
+    ref = torch.from_numpy(np.load(os.path.join(GOLDEN, "logconf_table.npy")))
+    assert torch.equal(so.log_conf_table(), ref)
+
+
+@pytest.mark.parametrize("name", list(SAMPLER_CASES))
+def test_sampler_trajectory_matches_reference(name):
+    """The whole sampler (text select, CFG, softmax/argmax, re-mask, write-back, schedules) driven by stub logits:
+    the ids handed to EVERY model call must equal what the reference's generate_ti2ti produced."""
+    z = np.load(os.path.join(GOLDEN, "sampler_traj.npz"))
+    calls_ref = torch.from_numpy(z[name + "_calls"])
+    seed = int(z[name + "_seed"])
+    job, kw = tiny_job(), SAMPLER_CASES[name]
+    V = STUB_TEXT_VOCAB + STUB_CB
+    n = [0]
+
+    def model_fn(ids):
+        n[0] += 1
+        return stub_logits(seed, n[0], ids.shape[0], ids.shape[1], V)
+
+    trace = []
+    final = generate_oracle.generate(model_fn, job["input_ids"], job["text_start"], job["text_end"], job["image_start"],
+                                     job["seq_len"], job["newline_every"], uncon_text=job["uncon_text"],
+                                     uncon_image=job["uncon_image"], text_vocab_size=STUB_TEXT_VOCAB,
+                                     codebook_size=STUB_CB, trace=trace, **kw)
+    got = torch.cat(trace, 0)
+    assert got.shape == calls_ref.shape
+    assert torch.equal(got, calls_ref), f"first differing call: {(got != calls_ref).any(1).nonzero()[0].item()}"
+    # final outputs: all non-MASK image tokens and the text must agree (the single MASK left is a random fill, A.1)
+    pos = [i for i in range(job["image_start"], job["image_start"] + job["seq_len"] + job["seq_len"] // job["newline_every"])
+           if int(job["input_ids"][0, i]) != synth.NEW_LINE]
+    vq_ref = z[name + "_vq"]
+    still = 0
+    for j, p in enumerate(pos):
+        tok = int(final[0, p])
+        if tok == synth.MASK:
+            still += 1
+        else:
+            assert tok - STUB_TEXT_VOCAB == vq_ref[j]
+    assert still == 1  # exactly one token is left for torch.randint
+    text = [t for t in final[0, job["text_start"]:job["text_end"]].tolist() if t != synth.MASK]
+    assert text == z[name + "_text"].tolist()
+
+
+def test_forward_matches_reference():
+    z = np.load(os.path.join(GOLDEN, "forward_tiny.npz"))
+    ids = torch.from_numpy(z["ids"])
+    sd, cfg = tiny_sd(), synth.CFG_TINY
+    taps = []
+    x = llada_oracle.forward_hidden(sd, cfg, ids, taps)
+    hidden_ref = from_bits(z["hidden"])
+    for i, t in enumerate(taps):
+        assert torch.equal(bits(t[0]), bits(hidden_ref[i])), f"block {i}"
+    pos = z["pos"].tolist()
+    img = llada_oracle.head(sd, cfg, x[:, pos], synth.TEXT_VOCAB, synth.TEXT_VOCAB + synth.CODEBOOK)
+    assert torch.equal(bits(img[0]), torch.from_numpy(z["img_logits"]))
+    job = tiny_job()
+    full = llada_oracle.head(sd, cfg, x)
+    assert torch.equal(full[0].argmax(-1).int(), torch.from_numpy(z["argmax"]))
+    assert torch.equal(bits(full[0, job["text_start"]:job["text_end"], :4096]), torch.from_numpy(z["text_logits_head"]))
+
+
+def test_e2e_tiny_matches_reference():
+    z = np.load(os.path.join(GOLDEN, "e2e_tiny.npz"))
+    sd, cfg, job = tiny_sd(), synth.CFG_TINY, tiny_job()
+    trace = []
+    generate_oracle.generate(lambda ids: llada_oracle.forward_logits(sd, cfg, ids), job["input_ids"], job["text_start"],
+                             job["text_end"], job["image_start"], job["seq_len"], job["newline_every"], text_steps=8,
+                             timesteps=4, cfg_scale=0.0, cfg_img=4.0, uncon_text=job["uncon_text"],
+                             uncon_image=job["uncon_image"], trace=trace)
+    assert torch.equal(torch.cat(trace, 0), torch.from_numpy(z["calls"]))
+
+
+def test_image_probs_against_torch_ops():
+    # parallel_generator.py:282-295 evaluated with the reference's own torch ops on seeded random logits
+    torch.manual_seed(3)
+    B, N, CB = 1, 64, 8192
+    c = (torch.randn(B, N, CB) * 1.5).to(torch.bfloat16)
+    ut = (c.float() + torch.randn(B, N, CB) * 0.5).to(torch.bfloat16)
+    ui = (c.float() + torch.randn(B, N, CB) * 0.5).to(torch.bfloat16)
+    for cs, ci in [(0.0, 4.0), (2.3, 4.0), (3.0, 0.0), (0.0, 0.0)]:
+        il = c
+        if cs != 0.0:
+            il = il + cs * (c - ut)
+        if ci != 0.0:
+            il = il + ci * (c - ui)
+        probs = F.softmax(il, dim=-1)
+        am_ref = probs.argmax(-1)
+        pm_ref = torch.gather(probs, -1, am_ref[..., None]).squeeze(-1)
+        am, pm, pr = so.image_probs(c, ut, ui, cs, ci, want_probs=True)
+        assert torch.equal(am.long(), am_ref)
+        assert torch.equal(bits(pm), bits(pm_ref))
+        # individual bf16 probabilities may differ in the last bit at rounding boundaries (libm exp / sum order)
+        assert (bits(pr) != bits(probs)).float().mean() < 1e-4
+
+
+def test_text_select_against_torch_ops():
+    # parallel_generator.py:185-217 with the reference's torch ops, B = 2
+    torch.manual_seed(5)
+    B, T, V, L, ts = 2, 24, 4096, 40, 10
+    logits = (torch.randn(B, T, V) * 2).to(torch.bfloat16)
+    ids = torch.randint(0, 1000, (B, L))
+    ids[:, ts:ts + T] = synth.MASK
+    ids[0, ts + 3] = 5
+    ids[1, ts + 7] = 9
+    k = [5, 9]
+    masked = ids[:, ts:ts + T] == synth.MASK
+    x0 = torch.argmax(logits, dim=-1)
+    p = F.softmax(logits.to(torch.float64), dim=-1)
+    x0_p = torch.gather(p, -1, x0[..., None]).squeeze(-1)
+    x0 = torch.where(masked, x0, ids[:, ts:ts + T])
+    conf = torch.where(masked, x0_p, -np.inf)
+    ref = ids.clone()
+    tr = torch.zeros_like(x0, dtype=torch.bool)
+    for j in range(B):
+        _, sel = torch.topk(conf[j], k=k[j])
+        tr[j, sel] = True
+    ref[:, ts:ts + T][tr] = x0[tr]
+    got, conf_o, _ = so.text_select(logits, None, ids, ts, k)
+    assert torch.equal(got, ref)
+    m = masked
+    assert torch.allclose(conf_o[m], x0_p[m], rtol=1e-12, atol=0)
+
+
+def test_lfq_gather_against_reference_formula():
+    # MMaDA-Parallel-M/models/modeling_magvitv2.py:186-194,208-221
+    nbits = 13
+    idx = torch.randint(0, 2 ** nbits, (2, 50))
+    mask = 2 ** torch.arange(nbits - 1, -1, -1)
+    ref = ((idx[..., None] & mask) != 0).float() * 2 - 1  # [B,N,nbits]
+    assert torch.equal(so.lfq_gather(idx, nbits), ref.permute(0, 2, 1).contiguous())
