@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Headline benchmark: images/sec of the MMaDA-Parallel-A 8B parallel text+image sampler on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one complete TI2TI job of BASELINE.json configs[1]: 512x512 output, text_steps=128, timesteps=64,
+cfg_scale=0, cfg_img=4.0, temperature=0, batch 1 per tensor-parallel group, L = 2438 tokens, 256 forwards of the 8B
+denoiser (128 conditional + 64 x 2 unconditional), synthetic weights / tokens (no checkpoint offline).
+With N GPUs the model is tensor-parallel over N ranks (RCCL all-reduce over xGMI) and the batch is N jobs (weak
+scaling, BASELINE configs[2]).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+KIND_NAMES = ["qkv_rope_gemm", "flash_attention", "attn_out_gemm", "gate_up_swiglu_gemm", "down_gemm"]
+
+
+def body_flops(cfg, L):
+    d, F, nl = cfg["d_model"], cfg["mlp_hidden_size"], cfg["n_layers"]
+    kv = (cfg.get("n_kv_heads") or cfg["n_heads"]) * (d // cfg["n_heads"])
+    lin = 2.0 * L * (d * d + 2 * d * kv + d * d + 3 * d * F)
+    return nl * (lin + 4.0 * L * L * d)
+
+
+def job_flops(cfg, L, T, N, text_steps, n_img_steps, V, CB):
+    """Algorithmic FLOPs of one image: LM head counted on the consumed rows/columns only."""
+    fb = body_flops(cfg, L)
+    head_text = 2.0 * T * cfg["d_model"] * V
+    head_img = 2.0 * N * cfg["d_model"] * CB
+    return text_steps * (fb + head_text) + n_img_steps * 2 * fb + n_img_steps * 3 * head_img
+
+
+def cpu_baseline(cfg, job, sample_layers=2, reps=2):
+    """Oracle (CPU restatement of the reference forward) timed on the host cores on a bounded sample:
+    `sample_layers` blocks + consumed LM-head rows at the full shape, extrapolated to 256 forwards / image."""
+    from mmada_parallel_amd import synth
+    from oracle import llada_oracle
+
+    small = dict(cfg, n_layers=sample_layers)
+    sd = synth.synthetic_state_dict(small, seed=0, device="cpu")
+    ids = job["input_ids"]
+    L = ids.shape[1]
+    T, N = job["text_end"] - job["text_start"], job["seq_len"]
+    t_layers, t_head = [], []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        x = llada_oracle.forward_hidden(sd, small, ids)
+        t1 = time.perf_counter()
+        llada_oracle.head(sd, small, x[:, job["text_start"]:job["text_end"]])
+        llada_oracle.head(sd, small, x[:, :N], synth.TEXT_VOCAB, synth.TEXT_VOCAB + synth.CODEBOOK)
+        t2 = time.perf_counter()
+        t_layers.append((t1 - t0) / sample_layers)
+        t_head.append(t2 - t1)
+    per_forward = min(t_layers) * cfg["n_layers"]
+    n_fwd = 128 + 2 * 64
+    per_image = n_fwd * per_forward + 128 * min(t_head)
+    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/llada_oracle.py forward of {sample_layers} of {cfg['n_layers']} blocks + consumed LM-head "
+                      f"rows at L={L} (best of {reps}), extrapolated to {n_fwd} forwards/image: "
+                      f"{per_forward:.2f} s/forward"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--text-steps", type=int, default=128, help="debug only: any other value marks the line reduced")
+    ap.add_argument("--timesteps", type=int, default=64, help="debug only")
+    ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (marks the line reduced)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from mmada_parallel_amd import LLaDAForMultiModalGeneration, abi, generate_ti2ti, synth
+
+    cfg = dict(synth.CFG_8B)
+    if args.layers:
+        cfg["n_layers"] = args.layers
+    reduced = args.text_steps != 128 or args.timesteps != 64 or args.layers is not None
+    full = synth.full_config(cfg)
+    B = world  # weak scaling: one job per rank-equivalent, model tensor-parallel over all ranks
+    sd = synth.synthetic_state_dict(cfg, seed=0, device=str(dev))
+    model = LLaDAForMultiModalGeneration.from_state_dict(full, sd, device=dev, tp_rank=rank, tp_size=world, max_batch=2 * B)
+    del sd
+    torch.cuda.empty_cache()
+
+    job = synth.synthetic_job(512, 512, text_gen_length=256, prompt_len=64, uncond_prompt_len=24, seed=1)
+    ids = job["input_ids"].repeat(B, 1).to(dev)
+    L = ids.shape[1]
+    T, N = job["text_end"] - job["text_start"], job["seq_len"]
+
+    def run_once():
+        return generate_ti2ti(model, ids, job["text_start"], job["text_end"], job["image_start"], job["seq_len"],
+                              job["newline_every"], text_steps=args.text_steps, timesteps=args.timesteps, temperature=0.0,
+                              text_temperature=0.0, cfg_scale=0.0, cfg_img=4.0, uncon_text=job["uncon_text"],
+                              uncon_image=job["uncon_image"])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        run_once()
+    lib, h = model._lib, model._handle
+    barrier()
+    abi.check(lib.mmada_profile_begin(h, cfg["n_layers"] // 2), "profile_begin")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        vq, _ = run_once()
+    barrier()
+    dt = time.perf_counter() - t0
+    cnt, ms, fl = (C.c_int32 * 5)(), (C.c_double * 5)(), (C.c_double * 5)()
+    abi.check(lib.mmada_profile_end(h, cnt, ms, fl), "profile_end")
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+
+    if rank == 0:
+        from mmada_parallel_amd.generators.parallel_generator import image_step_indices
+
+        n_img = len(set(image_step_indices(args.text_steps, args.timesteps)))
+        fl_img = job_flops(cfg, L, T, N, args.text_steps, n_img, cfg["embedding_size"], synth.CODEBOOK)
+        images = args.steps * B
+        value = images / dt
+        kinds = {}
+        for i, nm in enumerate(KIND_NAMES):
+            if cnt[i]:
+                kinds[nm] = {"launches": cnt[i], "avg_ms": ms[i] / cnt[i], "tflops": fl[i] / (ms[i] * 1e-3) / 1e12}
+        dom = max(range(5), key=lambda i: ms[i]) if any(cnt) else 3
+        ach = fl[dom] / (ms[dom] * 1e-3) / 1e12 if cnt[dom] else 0.0
+        out = {
+            "metric": "images/sec (512x512, 64 img + 128 text steps) MMaDA-Parallel-A 8B",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: MMaDA-Parallel-A 8B, 512x512, timesteps=64, text_steps=128, "
+                                   "cfg_img=4.0, temperature=0, L=2438, 256 forwards/image" + (" [REDUCED DEBUG RUN]" if reduced else ""),
+                       "global_batch": B, "seq_len": L, "parallelism": f"tp{world}",
+                       "text_steps": args.text_steps, "timesteps": args.timesteps, "n_layers": cfg["n_layers"],
+                       "algorithmic_pflop_per_image": fl_img / 1e15,
+                       "job_mfma_frac": value * fl_img / 1e12 / (world * MFMA_BF16_PEAK_TFLOPS),
+                       "kernels": kinds},
+            "roofline": {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, job)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -144,16 +144,25 @@ int mmada_image_probs(mmada_handle* h, const void* cond, const void* unc_text, c
  *   mask_len = clamp(max(1, min(unknown_count-1, *mask_len_sched)), 0, N-1); the mask_len lowest-confidence
  *   positions (stable order) are re-masked, all others get ids = sampled + text_vocab.
  * sampled_in: device int32 [B,N]; p_in: bf16 device [B,N]; noise: NULL or bf16 device [B,N] (randn, :30-33);
- * mask_len_sched: device int32 [1] = floor(N·cos(ratio·π/2)) for this step (:318-321). */
+ * mask_len_sched: device int32 [1] = floor(N·cos(ratio·π/2)) for this step (:318-321);
+ * text_vocab_size / codebook_size: the reference's call arguments of the same name (:124-125). */
 int mmada_image_commit(mmada_handle* h, int64_t* ids, int B, int L, const int32_t* pos_map, int N,
                        const int32_t* sampled_in, const void* p_in, const void* noise, float remask_temp,
-                       const int32_t* mask_len_sched, void* stream);
+                       const int32_t* mask_len_sched, int text_vocab_size, int codebook_size, void* stream);
 
 /* (M variant) LFQ codebook gather, MMaDA-Parallel-M/models/modeling_magvitv2.py:186-194,208-221:
  * out[b, c, n] = 2·bit_c(idx[b,n]) − 1 as bf16/f32, c in [0,nbits) with bit 0 = most significant
  * (mask = 2^(nbits-1-c)).  idx: device int64 [B,N]; out: device [B,nbits,N] (dtype_f32 ? float : bf16). */
 int mmada_lfq_gather(mmada_handle* h, const int64_t* idx, int B, int N, int nbits, int dtype_f32, void* out,
                      void* stream);
+
+/* ---- live kernel timing (bench.py's roofline leg) ---------------------------------------------------------------
+ * While enabled, the five hot kernels of block `layer` (0 qkv GEMM+RoPE, 1 attention, 2 attn_out GEMM, 3 gate/up
+ * GEMM+SiLU·mul, 4 down GEMM) are bracketed by hipEvents on the launch stream.  mmada_profile_end synchronises
+ * the events and returns, per kernel class, the launch count, the summed duration (ms) and the summed ALGORITHMIC
+ * flops (2·M·N·K with M = B·L real rows; attention 4·B·H·L²·128). */
+int mmada_profile_begin(mmada_handle* h, int layer);
+int mmada_profile_end(mmada_handle* h, int32_t* count_out /*[5]*/, double* ms_out /*[5]*/, double* flops_out /*[5]*/);
 
 /* ---- low-level kernels exposed for parity tests and profiling -------------------------------------------------- */
 

@@ -50,8 +50,10 @@ SIGNATURES = {
     "mmada_image_probs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "mmada_image_commit": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
-                                   c_float, c_void_p, c_void_p]),
+                                   c_float, c_void_p, c_int, c_int, c_void_p]),
     "mmada_lfq_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mmada_profile_begin": (c_int, [c_void_p, c_int]),
+    "mmada_profile_end": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "mmada_gemm_bt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mmada_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "mmada_sdpa": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

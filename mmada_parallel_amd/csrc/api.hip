@@ -49,7 +49,35 @@ struct mmada_handle {
     bf16_t *x = nullptr, *y = nullptr, *xn = nullptr, *att = nullptr, *hbuf = nullptr, *q = nullptr, *k = nullptr,
            *vT = nullptr, *xg = nullptr;
     int32_t* rows_all = nullptr;
+    // live timing (mmada_profile_begin/end)
+    int prof_layer = -1;
+    struct ProfRec { int kind; hipEvent_t a, b; double flops; };
+    std::vector<ProfRec> prof;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
 };
+
+namespace {
+struct ProfScope {
+    mmada_handle* h; hipStream_t s; bool on; hipEvent_t a{}, b{}; int kind; double flops;
+    ProfScope(mmada_handle* h_, int layer, int kind_, double flops_, hipStream_t s_)
+        : h(h_), s(s_), on(h_->prof_layer == layer), kind(kind_), flops(flops_) {
+        if (!on) return;
+        if (h->prof_pool.empty()) {
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+        } else {
+            a = h->prof_pool.back().first; b = h->prof_pool.back().second;
+            h->prof_pool.pop_back();
+        }
+        (void)hipEventRecord(a, s);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(b, s);
+        h->prof.push_back({kind, a, b, flops});
+    }
+};
+}  // namespace
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int ceil_to(int v, int a) { return (v + a - 1) / a * a; }
@@ -125,10 +153,11 @@ int mmada_create(const mmada_cfg* cfg, const float* inv_freq_host, mmada_handle*
 int mmada_destroy(mmada_handle* h) {
     if (!h) return 0;
     for (auto& lw : h->layers) {
-        hipFree(lw.wqkv); hipFree(lw.wo); hipFree(lw.wgu); hipFree(lw.wdown); hipFree(lw.attn_norm); hipFree(lw.ff_norm);
+        (void)hipFree(lw.wqkv); (void)hipFree(lw.wo); (void)hipFree(lw.wgu);
+        (void)hipFree(lw.wdown); (void)hipFree(lw.attn_norm); (void)hipFree(lw.ff_norm);
     }
-    hipFree(h->rope_cos);
-    hipFree(h->rope_sin);
+    (void)hipFree(h->rope_cos);
+    (void)hipFree(h->rope_sin);
     delete h;
     return 0;
 }
@@ -233,15 +262,25 @@ int mmada_attn_partial(mmada_handle* h, int layer, void* stream) {
     g.lda = d; g.ldw = d; g.ldc = 0;
     g.q = h->q; g.k = h->k; g.vT = h->vT; g.rope_cos = h->rope_cos; g.rope_sin = h->rope_sin;
     g.Lp = h->Lp; g.Lkv = h->Lkv; g.Hq = h->hq_l; g.Hkv = h->hkv_l;
-    if (launch_gemm(EPI_QKV, g, s)) return 1;
-    if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->Lp, h->Lkv, h->Lp, h->hq_l * 128, s))
-        return 1;
+    const double rows = (double)h->B * h->L;
+    {
+        ProfScope p(h, layer, 0, 2.0 * rows * g.N * g.K, s);
+        if (launch_gemm(EPI_QKV, g, s)) return 1;
+    }
+    {
+        ProfScope p(h, layer, 1, 4.0 * h->B * h->hq_l * (double)h->L * h->L * 128.0, s);
+        if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->Lp, h->Lkv, h->Lp,
+                             h->hq_l * 128, s)) return 1;
+    }
     GemmArgs o{};
     o.A = h->att; o.W = lw.wo; o.C = h->y;
     o.M = h->M; o.N = d; o.K = h->hq_l * 128;
     o.lda = o.K; o.ldw = o.K; o.ldc = d;
     o.resid = h->x; o.ldr = d; o.add_resid = (h->cfg.tp_rank == 0);
-    if (launch_gemm(EPI_RESID, o, s)) return 1;
+    {
+        ProfScope p(h, layer, 2, 2.0 * rows * o.N * o.K, s);
+        if (launch_gemm(EPI_RESID, o, s)) return 1;
+    }
     std::swap(h->x, h->y);
     return 0;
 }
@@ -257,14 +296,44 @@ int mmada_mlp_partial(mmada_handle* h, int layer, void* stream) {
     g.A = h->xn; g.W = lw.wgu; g.C = h->hbuf;
     g.M = h->M; g.N = 2 * h->f_l; g.K = d;
     g.lda = d; g.ldw = d; g.ldc = h->f_l;
-    if (launch_gemm(EPI_SWIGLU, g, s)) return 1;
+    const double rows = (double)h->B * h->L;
+    {
+        ProfScope p(h, layer, 3, 2.0 * rows * g.N * g.K, s);
+        if (launch_gemm(EPI_SWIGLU, g, s)) return 1;
+    }
     GemmArgs o{};
     o.A = h->hbuf; o.W = lw.wdown; o.C = h->y;
     o.M = h->M; o.N = d; o.K = h->f_l;
     o.lda = h->f_l; o.ldw = h->f_l; o.ldc = d;
     o.resid = h->x; o.ldr = d; o.add_resid = (h->cfg.tp_rank == 0);
-    if (launch_gemm(EPI_RESID, o, s)) return 1;
+    {
+        ProfScope p(h, layer, 4, 2.0 * rows * o.N * o.K, s);
+        if (launch_gemm(EPI_RESID, o, s)) return 1;
+    }
     std::swap(h->x, h->y);
+    return 0;
+}
+
+int mmada_profile_begin(mmada_handle* h, int layer) {
+    if (!h) return mm_fail("mmada_profile_begin: null handle");
+    for (auto& r : h->prof) h->prof_pool.push_back({r.a, r.b});
+    h->prof.clear();
+    h->prof_layer = layer;
+    return 0;
+}
+
+int mmada_profile_end(mmada_handle* h, int32_t* count_out, double* ms_out, double* flops_out) {
+    if (!h || !count_out || !ms_out || !flops_out) return mm_fail("mmada_profile_end: null argument");
+    for (int i = 0; i < 5; ++i) { count_out[i] = 0; ms_out[i] = 0.0; flops_out[i] = 0.0; }
+    for (auto& r : h->prof) {
+        MM_CHECK_HIP(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        MM_CHECK_HIP(hipEventElapsedTime(&ms, r.a, r.b));
+        count_out[r.kind] += 1; ms_out[r.kind] += ms; flops_out[r.kind] += r.flops;
+        h->prof_pool.push_back({r.a, r.b});
+    }
+    h->prof.clear();
+    h->prof_layer = -1;
     return 0;
 }
 
@@ -330,11 +399,10 @@ int mmada_image_probs(mmada_handle* h, const void* cond, const void* unc_text, c
 
 int mmada_image_commit(mmada_handle* h, int64_t* ids, int B, int L, const int32_t* pos_map, int N,
                        const int32_t* sampled_in, const void* p_in, const void* noise, float remask_temp,
-                       const int32_t* mask_len_sched, void* stream) {
+                       const int32_t* mask_len_sched, int text_vocab_size, int codebook_size, void* stream) {
     if (!h || !ids || !pos_map || !sampled_in || !p_in || !mask_len_sched) return mm_fail("mmada_image_commit: null argument");
     return launch_image_commit(ids, B, L, pos_map, N, sampled_in, (const bf16_t*)p_in, (const bf16_t*)noise, remask_temp,
-                               mask_len_sched, h->cfg.mask_token_id, h->cfg.text_vocab_size, h->cfg.codebook_size,
-                               (hipStream_t)stream);
+                               mask_len_sched, h->cfg.mask_token_id, text_vocab_size, codebook_size, (hipStream_t)stream);
 }
 
 int mmada_lfq_gather(mmada_handle* h, const int64_t* idx, int B, int N, int nbits, int dtype_f32, void* out,

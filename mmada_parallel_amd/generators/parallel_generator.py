@@ -213,7 +213,8 @@ def generate_ti2ti(
                 noise = torch.randn((B, N), dtype=torch.bfloat16, device=device)
             abi.check(lib.mmada_image_commit(h, ids.data_ptr(), B, L, pos_map.data_ptr(), N, sampled.data_ptr(),
                                              p_sel.data_ptr(), noise.data_ptr(), float(img_temp),
-                                             mlen_dev[step:step + 1].data_ptr(), st), "mmada_image_commit")
+                                             mlen_dev[step:step + 1].data_ptr(), int(text_vocab_size),
+                                             int(codebook_size), st), "mmada_image_commit")
 
     # ===== final read-out (reference :346-368) =====
     final_ids = ids.cpu()

@@ -1,0 +1,245 @@
+"""GPU parity tests of the individual HIP kernels, called through the C-ABI (libmmada_mi355x.so).
+
+Integer / index results (argmax, selections, written ids) must be BIT-EXACT against the CPU oracle.
+Floating-point kernels (GEMM, RMSNorm, attention) are compared with an fp32 evaluation of the same op on the same
+bf16 inputs; the tolerance is stated at each assert (bf16 has 8 significant bits: 1 ulp = 2^-8 relative).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import bits
+from mmada_parallel_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def st():
+    return abi.stream_ptr()
+
+
+@pytest.fixture(scope="module")
+def handle():
+    """A tiny handle: the sampler / sdpa entry points only need cfg (mask id, vocab offsets) and a workspace."""
+    lib = abi.lib()
+    c = abi.MmadaCfg(d_model=256, n_layers=1, n_heads=2, n_kv_heads=2, head_dim=128, mlp_hidden=512, vocab=134656,
+                     max_seq=1024, rms_eps=1e-5, rope_theta=500000.0, tp_rank=0, tp_size=1, mask_token_id=synth.MASK,
+                     text_vocab_size=synth.TEXT_VOCAB, codebook_size=synth.CODEBOOK, reserved=0)
+    h = C.c_void_p()
+    abi.check(lib.mmada_create(C.byref(c), None, C.byref(h)), "create")
+    ws = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
+    base = (ws.data_ptr() + 255) // 256 * 256
+    abi.check(lib.mmada_set_workspace(h, base, ws.numel() - 256), "set_workspace")
+    yield h
+    lib.mmada_destroy(h)
+    del ws
+
+
+# ---------------------------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 256), (77, 200, 128), (1000, 8192, 256),
+                                   (2438, 4096, 4096), (2440, 12288, 4096)])
+def test_gemm_bt(M, N, K):
+    torch.manual_seed(M + N + K)
+    A = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    W = (torch.randn(N, K, device=DEV) * 0.05).to(torch.bfloat16)  # asymmetric operands: catches transposed C
+    Cout = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    abi.check(abi.lib().mmada_gemm_bt(A.data_ptr(), W.data_ptr(), Cout.data_ptr(), M, N, K, st()), "gemm")
+    ref = A.float() @ W.float().t()
+    err = (Cout.float() - ref).abs()
+    scale = ref.abs().max().item()
+    # fp32 accumulation, one bf16 rounding of the result: |err| <= 2^-9 |ref| + accumulation-order noise
+    assert torch.isfinite(Cout.float()).all()
+    assert (err <= 2.0 ** -8 * ref.abs() + 1e-3 * scale).all(), f"max err {err.max().item()} scale {scale}"
+
+
+# ------------------------------------------------------------------------------------------------------------- RMSNorm
+@pytest.mark.parametrize("rows,d", [(5, 256), (70, 4096), (2440, 4096)])
+def test_rmsnorm(rows, d):
+    from oracle import llada_oracle
+
+    torch.manual_seed(rows)
+    x = (torch.randn(rows, d) * 3).to(torch.bfloat16)
+    w = (1 + 0.02 * torch.randn(d)).to(torch.bfloat16)
+    out = torch.empty(rows, d, dtype=torch.bfloat16, device=DEV)
+    xd, wd = x.to(DEV), w.to(DEV)
+    abi.check(abi.lib().mmada_rmsnorm(xd.data_ptr(), wd.data_ptr(), out.data_ptr(), rows, d, 1e-5, st()), "rmsnorm")
+    ref = llada_oracle.rms_norm(x, w, 1e-5)
+    diff = (out.cpu().float() - ref.float()).abs()
+    # same rounding sequence as the reference; the fp32 sum order may move a value across one bf16 boundary
+    assert (diff <= 2.0 ** -7 * ref.float().abs() + 1e-6).all()
+    assert (bits(out) != bits(ref)).float().mean() < 5e-3
+
+
+# ----------------------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,H,Hkv,L", [(1, 2, 2, 70), (2, 2, 1, 333), (1, 4, 4, 1000), (1, 2, 2, 64), (1, 1, 1, 1),
+                                       (1, 2, 2, 2438)])
+def test_sdpa(handle, B, H, Hkv, L):
+    torch.manual_seed(L)
+    q = torch.randn(B, H, L, 128).to(torch.bfloat16)
+    k = torch.randn(B, Hkv, L, 128).to(torch.bfloat16)
+    v = torch.randn(B, Hkv, L, 128).to(torch.bfloat16)
+    out = torch.full((B, L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    abi.check(abi.lib().mmada_sdpa(handle, qd.data_ptr(), kd.data_ptr(), vd.data_ptr(), out.data_ptr(), B, H, Hkv, L, st()),
+              "sdpa")
+    kk, vv = k.float(), v.float()
+    if Hkv != H:
+        kk, vv = kk.repeat_interleave(H // Hkv, 1), vv.repeat_interleave(H // Hkv, 1)
+    ref = F.scaled_dot_product_attention(q.float(), kk, vv).transpose(1, 2).reshape(B, L, H * 128)
+    got = out.cpu().float()
+    assert torch.isfinite(got).all()
+    # P is rounded to bf16 before PV (as torch's bf16 flash kernel does): abs error ~ 2^-8 * |v| / sqrt(n_eff)
+    assert (got - ref).abs().max().item() < 2e-2, (got - ref).abs().max().item()
+    assert (got - ref).abs().mean().item() < 2e-3
+
+
+# -------------------------------------------------------------------------------------------------------- text sampler
+def _text_inputs(B, T, V, L, ts, seed, quantise=None):
+    g = torch.Generator().manual_seed(seed)
+    logits = torch.randn(B, T, V, generator=g) * 2
+    if quantise:  # coarse grid -> many exact ties, exercises lowest-index argmax
+        logits = (logits * quantise).round() / quantise
+    logits = logits.to(torch.bfloat16)
+    ids = torch.randint(0, 1000, (B, L), generator=g)
+    ids[:, ts:ts + T] = synth.MASK
+    for b in range(B):  # a few already-unmasked positions
+        ids[b, ts + torch.randperm(T, generator=g)[: T // 5]] = 7 + b
+    return logits, ids
+
+
+@pytest.mark.parametrize("B,T,V,k,quant", [(1, 16, 2560, [3], None), (2, 64, 134656, [5, 0], None),
+                                           (2, 256, 134656, [2, 7], 2), (1, 40, 4100, [32], 1), (3, 33, 1000, [1, 2, 3], None)])
+def test_text_select_bit_exact(handle, B, T, V, k, quant):
+    from oracle import sampler_oracle as so
+
+    L, ts = T + 20, 9
+    ld = (V + 7) // 8 * 8
+    logits, ids = _text_inputs(B, T, V, L, ts, seed=T + V, quantise=quant)
+    lpad = torch.zeros(B, T, ld, dtype=torch.bfloat16)
+    lpad[..., :V] = logits
+    ld_dev, ids_dev = lpad.to(DEV), ids.to(DEV)
+    k_dev = torch.tensor(k, dtype=torch.int32, device=DEV)
+    scratch = torch.empty(B * T * 16, dtype=torch.uint8, device=DEV)
+    abi.check(abi.lib().mmada_text_select(handle, ld_dev.data_ptr(), None, B, T, V, ld, ids_dev.data_ptr(), L, ts,
+                                          k_dev.data_ptr(), scratch.data_ptr(), st()), "text_select")
+    ref, conf_ref, x0_ref = so.text_select(logits, None, ids, ts, k)
+    assert torch.equal(ids_dev.cpu(), ref)
+    conf = scratch[: B * T * 8].view(torch.float64).cpu().view(B, T)
+    x0 = scratch[B * T * 8: B * T * 12].view(torch.int32).cpu().view(B, T)
+    assert torch.equal(x0, x0_ref)
+    m = torch.isfinite(conf_ref)
+    assert torch.equal(torch.isfinite(conf), m)
+    assert torch.allclose(conf[m], conf_ref[m], rtol=1e-12, atol=0)
+
+
+def test_text_select_with_noisy_argmax(handle):
+    from oracle import sampler_oracle as so
+
+    B, T, V, L, ts = 2, 32, 8192, 60, 5
+    logits, ids = _text_inputs(B, T, V, L, ts, seed=11)
+    noisy = (logits.float() + torch.randn(B, T, V, generator=torch.Generator().manual_seed(1))).to(torch.bfloat16)
+    k = [4, 6]
+    ids_dev, lg, nz = ids.to(DEV), logits.to(DEV), noisy.to(DEV)
+    k_dev = torch.tensor(k, dtype=torch.int32, device=DEV)
+    scratch = torch.empty(B * T * 16, dtype=torch.uint8, device=DEV)
+    abi.check(abi.lib().mmada_text_select(handle, lg.data_ptr(), nz.data_ptr(), B, T, V, V, ids_dev.data_ptr(), L, ts,
+                                          k_dev.data_ptr(), scratch.data_ptr(), st()), "text_select")
+    ref, _, _ = so.text_select(logits, noisy, ids, ts, k)
+    assert torch.equal(ids_dev.cpu(), ref)
+
+
+# ------------------------------------------------------------------------------------------------------- image sampler
+@pytest.mark.parametrize("B,N,CB,cs,ci,quant", [(1, 64, 8192, 0.0, 4.0, None), (2, 100, 8192, 2.5, 4.0, None),
+                                                (1, 1024, 8192, 2.3, 0.0, None), (1, 50, 512, 0.0, 0.0, 4),
+                                                (3, 16, 8192, 3.0, 4.0, 2)])
+def test_image_probs_bit_exact(handle, B, N, CB, cs, ci, quant):
+    from oracle import sampler_oracle as so
+
+    g = torch.Generator().manual_seed(N + CB)
+    c = torch.randn(B, N, CB, generator=g) * 1.5
+    if quant:
+        c = (c * quant).round() / quant
+    c = c.to(torch.bfloat16)
+    ut = (c.float() + torch.randn(B, N, CB, generator=g) * 0.5).to(torch.bfloat16)
+    ui = (c.float() + torch.randn(B, N, CB, generator=g) * 0.5).to(torch.bfloat16)
+    cd, utd, uid = c.to(DEV), ut.to(DEV), ui.to(DEV)
+    probs = torch.empty(B, N, CB, dtype=torch.bfloat16, device=DEV)
+    am = torch.empty(B, N, dtype=torch.int32, device=DEV)
+    pm = torch.empty(B, N, dtype=torch.bfloat16, device=DEV)
+    abi.check(abi.lib().mmada_image_probs(handle, cd.data_ptr(), utd.data_ptr(), uid.data_ptr(), B, N, CB, cs, ci,
+                                          probs.data_ptr(), am.data_ptr(), pm.data_ptr(), st()), "image_probs")
+    am_r, pm_r, pr_r = so.image_probs(c, ut, ui, cs, ci, want_probs=True)
+    assert torch.equal(am.cpu(), am_r)
+    assert torch.equal(bits(pm), bits(pm_r))
+    assert torch.equal(bits(probs), bits(pr_r))
+
+
+@pytest.mark.parametrize("case", ["fresh", "half_known", "all_known", "one_unknown", "noise"])
+def test_image_commit_bit_exact(handle, case):
+    from oracle import sampler_oracle as so
+
+    g = torch.Generator().manual_seed({"fresh": 1, "half_known": 2, "all_known": 3, "one_unknown": 4, "noise": 5}[case])
+    B, N, L = 2, 256, 400
+    pos = torch.sort(torch.randperm(L - 10, generator=g)[:N]).values + 5
+    ids = torch.randint(0, 1000, (B, L), generator=g)
+    known = {"fresh": 0, "half_known": N // 2, "all_known": N, "one_unknown": N - 1, "noise": N // 3}[case]
+    for b in range(B):
+        perm = torch.randperm(N, generator=g)
+        ids[b, pos] = synth.MASK
+        kn = pos[perm[:known]]
+        ids[b, kn] = synth.TEXT_VOCAB + torch.randint(0, synth.CODEBOOK, (known,), generator=g)
+    sampled = torch.randint(0, synth.CODEBOOK, (B, N), generator=g, dtype=torch.int32)
+    # bf16 probabilities from a coarse set -> massive ties in the log-confidence (stable order matters)
+    p = (torch.randint(1, 40, (B, N), generator=g).float() / 4096).to(torch.bfloat16)
+    noise = torch.randn(B, N, generator=g).to(torch.bfloat16) if case == "noise" else torch.zeros(B, N, dtype=torch.bfloat16)
+    temp = 0.37 if case == "noise" else 0.0
+    for mlen in (-1, 0, 1, 17, N // 2, N + 5):
+        ids_dev = ids.to(DEV)
+        ml = torch.tensor([mlen], dtype=torch.int32, device=DEV)
+        abi.check(abi.lib().mmada_image_commit(handle, ids_dev.data_ptr(), B, L, pos.to(torch.int32).to(DEV).data_ptr(), N,
+                                               sampled.to(DEV).data_ptr(), p.to(DEV).data_ptr(), noise.to(DEV).data_ptr(),
+                                               temp, ml.data_ptr(), synth.TEXT_VOCAB, synth.CODEBOOK, st()), "image_commit")
+        ref = so.image_commit(ids, pos.to(torch.int32), sampled, p, noise, temp, mlen)
+        assert torch.equal(ids_dev.cpu(), ref), f"{case} mlen={mlen}"
+
+
+def test_log_conf_all_bf16_probabilities(handle, golden_dir):
+    """image_commit's bf16 log-confidence for EVERY non-negative bf16 probability, checked through its observable
+    effect: ranking N tokens whose probabilities enumerate all bit patterns must give the oracle's ids."""
+    from oracle import sampler_oracle as so
+
+    vals = torch.arange(0, 0x7f80, dtype=torch.int32)
+    chunks = vals.split(4096)
+    for ci, ch in enumerate(chunks):
+        N = ch.numel()
+        L = N + 4
+        pos = torch.arange(2, 2 + N, dtype=torch.int32)
+        ids = torch.full((1, L), synth.MASK, dtype=torch.long)
+        perm = torch.randperm(N, generator=torch.Generator().manual_seed(ci))
+        p = ch.to(torch.int16).view(torch.bfloat16)[perm].view(1, N)
+        sampled = torch.zeros(1, N, dtype=torch.int32)
+        noise = torch.zeros(1, N, dtype=torch.bfloat16)
+        for mlen in (N // 3, N - 2):
+            ids_dev = ids.to(DEV)
+            ml = torch.tensor([mlen], dtype=torch.int32, device=DEV)
+            abi.check(abi.lib().mmada_image_commit(handle, ids_dev.data_ptr(), 1, L, pos.to(DEV).data_ptr(), N,
+                                                   sampled.to(DEV).data_ptr(), p.to(DEV).data_ptr(),
+                                                   noise.to(DEV).data_ptr(), 0.0, ml.data_ptr(), synth.TEXT_VOCAB,
+                                                   synth.CODEBOOK, st()), "image_commit")
+            assert torch.equal(ids_dev.cpu(), so.image_commit(ids, pos, sampled, p, noise, 0.0, mlen))
+
+
+def test_lfq_gather(handle):
+    from oracle import sampler_oracle as so
+
+    idx = torch.randint(0, 2 ** 13, (2, 1024))
+    out = torch.empty(2, 13, 1024, dtype=torch.float32, device=DEV)
+    abi.check(abi.lib().mmada_lfq_gather(handle, idx.to(DEV).data_ptr(), 2, 1024, 13, 1, out.data_ptr(), st()), "lfq")
+    assert torch.equal(out.cpu(), so.lfq_gather(idx, 13))
+    outb = torch.empty(2, 13, 1024, dtype=torch.bfloat16, device=DEV)
+    abi.check(abi.lib().mmada_lfq_gather(handle, idx.to(DEV).data_ptr(), 2, 1024, 13, 0, outb.data_ptr(), st()), "lfq")
+    assert torch.equal(outb.cpu().float(), so.lfq_gather(idx, 13))
