@@ -115,6 +115,11 @@ size_t mmada_stream_bytes(const mmada_handle* h);
 
 /* Debug / parity taps: copy the residual stream rows [b*L+l] (pad rows dropped) to out bf16 [B*L, d]. */
 int mmada_read_stream(mmada_handle* h, void* out, void* stream);
+/* Parity tap on the intermediates of the most recent block: which = 0 xn [B*Lp,d] (last RMSNorm output),
+ * 1 q [B,Hq,Lkv,128] (after RoPE), 2 k [B,Hkv,Lkv,128] (after RoPE), 3 vT [B,Hkv,128,Lkv], 4 att [B*Lp,Hq*128]
+ * (SDPA output, heads merged), 5 h [B*Lp,F] (silu(ff_proj)*up_proj).  Returns the device pointer and the padded
+ * dims {Lp, Lkv} so tests can slice.  The buffers live in the caller's workspace. */
+int mmada_debug_buffer(mmada_handle* h, int which, void** ptr_out, int32_t* lp_out, int32_t* lkv_out);
 
 /* ---- sampler math (generators/parallel_generator.py) ---------------------------------------------------------- */
 

@@ -45,6 +45,7 @@ SIGNATURES = {
     "mmada_stream_ptr": (c_void_p, [c_void_p]),
     "mmada_stream_bytes": (c_size_t, [c_void_p]),
     "mmada_read_stream": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "mmada_debug_buffer": (c_int, [c_void_p, c_int, C.POINTER(c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mmada_text_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p]),
     "mmada_image_probs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,

@@ -381,6 +381,16 @@ int mmada_read_stream(mmada_handle* h, void* out, void* stream) {
     return launch_unpad_rows(h->x, (bf16_t*)out, h->B, h->L, h->Lp, h->cfg.d_model, (hipStream_t)stream);
 }
 
+int mmada_debug_buffer(mmada_handle* h, int which, void** ptr_out, int32_t* lp_out, int32_t* lkv_out) {
+    if (!h || h->M == 0 || !ptr_out) return mm_fail("mmada_debug_buffer: no forward resident");
+    bf16_t* tab[6] = {h->xn, h->q, h->k, h->vT, h->att, h->hbuf};
+    if (which < 0 || which > 5) return mm_fail("mmada_debug_buffer: which=%d", which);
+    *ptr_out = tab[which];
+    if (lp_out) *lp_out = h->Lp;
+    if (lkv_out) *lkv_out = h->Lkv;
+    return 0;
+}
+
 int mmada_text_select(mmada_handle* h, const void* logits, const void* noisy, int B, int T, int V, int ld_logits,
                       int64_t* ids, int L, int text_start, const int32_t* k, void* scratch, void* stream) {
     if (!h || !logits || !ids || !k || !scratch) return mm_fail("mmada_text_select: null argument");

@@ -200,6 +200,22 @@ class LLaDAForMultiModalGeneration:
         abi.check(self._lib.mmada_read_stream(self._handle, out.data_ptr(), abi.stream_ptr()), "mmada_read_stream")
         return out
 
+    def debug_buffer(self, which: int) -> torch.Tensor:
+        """Parity tap (tests only): flat bf16 view of an intermediate of the most recent block, see mmada_debug_buffer."""
+        p, lp, lkv = C.c_void_p(), C.c_int32(), C.c_int32()
+        abi.check(self._lib.mmada_debug_buffer(self._handle, which, C.byref(p), C.byref(lp), C.byref(lkv)), "debug_buffer")
+        B, L = self._shape
+        d, F = self.config.d_model, self.mlp_hidden // self.tp_size
+        hq, hkv = self.config.n_heads // self.tp_size, self.n_kv_heads // self.tp_size
+        shapes = {0: (B * lp.value, d), 1: (B, hq, lkv.value, 128), 2: (B, hkv, lkv.value, 128),
+                  3: (B, hkv, 128, lkv.value), 4: (B * lp.value, hq * 128), 5: (B * lp.value, F)}
+        shape = shapes[which]
+        n = 2
+        for v in shape:
+            n *= v
+        off = p.value - self._ws.data_ptr()
+        return self._ws[off:off + n].view(torch.bfloat16).view(*shape)
+
     def forward(self, input_ids=None, labels=None, infer=False, use_cache=False, **_):
         if not infer or labels is not None:
             raise NotImplementedError("only forward(infer=True) is on the MI355X hot path (training loss is out of scope)")

@@ -69,8 +69,9 @@ def test_rmsnorm(rows, d):
     abi.check(abi.lib().mmada_rmsnorm(xd.data_ptr(), wd.data_ptr(), out.data_ptr(), rows, d, 1e-5, st()), "rmsnorm")
     ref = llada_oracle.rms_norm(x, w, 1e-5)
     diff = (out.cpu().float() - ref.float()).abs()
-    # same rounding sequence as the reference; the fp32 sum order may move a value across one bf16 boundary
-    assert (diff <= 2.0 ** -7 * ref.float().abs() + 1e-6).all()
+    # same rounding sequence as the reference; the fp32 sum order may move the normalised value across one bf16
+    # boundary (1 ulp = 2^-8..2^-7 relative) before the second rounding of w*y
+    assert (diff <= 2.0 ** -6 * ref.float().abs() + 1e-6).all()
     assert (bits(out) != bits(ref)).float().mean() < 5e-3
 
 
@@ -197,12 +198,13 @@ def test_image_commit_bit_exact(handle, case):
     p = (torch.randint(1, 40, (B, N), generator=g).float() / 4096).to(torch.bfloat16)
     noise = torch.randn(B, N, generator=g).to(torch.bfloat16) if case == "noise" else torch.zeros(B, N, dtype=torch.bfloat16)
     temp = 0.37 if case == "noise" else 0.0
+    pos_d, samp_d, p_d, noise_d = pos.to(torch.int32).to(DEV), sampled.to(DEV), p.to(DEV), noise.to(DEV)  # keep alive
     for mlen in (-1, 0, 1, 17, N // 2, N + 5):
         ids_dev = ids.to(DEV)
         ml = torch.tensor([mlen], dtype=torch.int32, device=DEV)
-        abi.check(abi.lib().mmada_image_commit(handle, ids_dev.data_ptr(), B, L, pos.to(torch.int32).to(DEV).data_ptr(), N,
-                                               sampled.to(DEV).data_ptr(), p.to(DEV).data_ptr(), noise.to(DEV).data_ptr(),
-                                               temp, ml.data_ptr(), synth.TEXT_VOCAB, synth.CODEBOOK, st()), "image_commit")
+        abi.check(abi.lib().mmada_image_commit(handle, ids_dev.data_ptr(), B, L, pos_d.data_ptr(), N, samp_d.data_ptr(),
+                                               p_d.data_ptr(), noise_d.data_ptr(), temp, ml.data_ptr(), synth.TEXT_VOCAB,
+                                               synth.CODEBOOK, st()), "image_commit")
         ref = so.image_commit(ids, pos.to(torch.int32), sampled, p, noise, temp, mlen)
         assert torch.equal(ids_dev.cpu(), ref), f"{case} mlen={mlen}"
 
@@ -223,13 +225,13 @@ def test_log_conf_all_bf16_probabilities(handle, golden_dir):
         p = ch.to(torch.int16).view(torch.bfloat16)[perm].view(1, N)
         sampled = torch.zeros(1, N, dtype=torch.int32)
         noise = torch.zeros(1, N, dtype=torch.bfloat16)
+        pos_d, samp_d, p_d, noise_d = pos.to(DEV), sampled.to(DEV), p.to(DEV), noise.to(DEV)  # keep alive
         for mlen in (N // 3, N - 2):
             ids_dev = ids.to(DEV)
             ml = torch.tensor([mlen], dtype=torch.int32, device=DEV)
-            abi.check(abi.lib().mmada_image_commit(handle, ids_dev.data_ptr(), 1, L, pos.to(DEV).data_ptr(), N,
-                                                   sampled.to(DEV).data_ptr(), p.to(DEV).data_ptr(),
-                                                   noise.to(DEV).data_ptr(), 0.0, ml.data_ptr(), synth.TEXT_VOCAB,
-                                                   synth.CODEBOOK, st()), "image_commit")
+            abi.check(abi.lib().mmada_image_commit(handle, ids_dev.data_ptr(), 1, L, pos_d.data_ptr(), N,
+                                                   samp_d.data_ptr(), p_d.data_ptr(), noise_d.data_ptr(), 0.0,
+                                                   ml.data_ptr(), synth.TEXT_VOCAB, synth.CODEBOOK, st()), "image_commit")
             assert torch.equal(ids_dev.cpu(), so.image_commit(ids, pos, sampled, p, noise, 0.0, mlen))
 
 
@@ -237,9 +239,10 @@ def test_lfq_gather(handle):
     from oracle import sampler_oracle as so
 
     idx = torch.randint(0, 2 ** 13, (2, 1024))
+    idx_d = idx.to(DEV)
     out = torch.empty(2, 13, 1024, dtype=torch.float32, device=DEV)
-    abi.check(abi.lib().mmada_lfq_gather(handle, idx.to(DEV).data_ptr(), 2, 1024, 13, 1, out.data_ptr(), st()), "lfq")
+    abi.check(abi.lib().mmada_lfq_gather(handle, idx_d.data_ptr(), 2, 1024, 13, 1, out.data_ptr(), st()), "lfq")
     assert torch.equal(out.cpu(), so.lfq_gather(idx, 13))
     outb = torch.empty(2, 13, 1024, dtype=torch.bfloat16, device=DEV)
-    abi.check(abi.lib().mmada_lfq_gather(handle, idx.to(DEV).data_ptr(), 2, 1024, 13, 0, outb.data_ptr(), st()), "lfq")
+    abi.check(abi.lib().mmada_lfq_gather(handle, idx_d.data_ptr(), 2, 1024, 13, 0, outb.data_ptr(), st()), "lfq")
     assert torch.equal(outb.cpu().float(), so.lfq_gather(idx, 13))

@@ -30,6 +30,80 @@ def tiny_model():
 
 
 # ------------------------------------------------------------------------------------------------ (ii) model tolerance
+def _relerr(got, ref):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    return ((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)).item(), \
+           ((got - ref).abs().mean() / ref.abs().mean().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_block_stages_vs_oracle(tiny_model, B):
+    """Every intermediate of block 0 (RMSNorm, q/k after RoPE, V, SDPA output, residual adds, SiLU-gated hidden)
+    against the oracle's value of the same tensor; errors are relative to each tensor's own magnitude, so a wrong
+    branch cannot hide behind the (much larger) residual stream."""
+    import torch.nn.functional as F
+    from mmada_parallel_amd import abi
+    from oracle import llada_oracle as lo
+
+    sd, cfg = tiny_sd(), synth.CFG_TINY
+    job = tiny_job()
+    ids = job["input_ids"].repeat(B, 1)
+    if B > 1:
+        ids[1, :8] = torch.arange(100, 108)
+    L = ids.shape[1]
+    H, Hkv, hd, eps = cfg["n_heads"], cfg["n_kv_heads"], 128, cfg["rms_norm_eps"]
+    w = lo.layer_weights(sd, 0)
+    x0 = F.embedding(ids, sd["model.transformer.wte.weight"])
+    xn = lo.rms_norm(x0, w["attn_norm"], eps)
+    q = F.linear(xn, w["q_proj"]).view(B, L, H, hd).transpose(1, 2)
+    k = F.linear(xn, w["k_proj"]).view(B, L, Hkv, hd).transpose(1, 2)
+    v = F.linear(xn, w["v_proj"]).view(B, L, Hkv, hd).transpose(1, 2)
+    sin, cos = lo.rope_tables(L, hd, cfg["rope_theta"])
+    q, k = lo.apply_rope(q, sin, cos), lo.apply_rope(k, sin, cos)
+    att = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).contiguous().view(B, L, H * hd)
+    x1 = x0 + F.linear(att, w["attn_out"])
+    n2 = lo.rms_norm(x1, w["ff_norm"], eps)
+    hmid = F.silu(F.linear(n2, w["ff_proj"])) * F.linear(n2, w["up_proj"])
+    x2 = x1 + F.linear(hmid, w["ff_out"])
+
+    lib, h = tiny_model._lib, tiny_model._handle
+    ids_d = ids.to(DEV)
+    tiny_model._ensure_ws(B, L)
+    tiny_model._shape = (B, L)
+    st = abi.stream_ptr()
+    abi.check(lib.mmada_embed(h, ids_d.data_ptr(), B, L, st), "embed")
+    e_x0 = _relerr(tiny_model.hidden_state(), x0)
+    abi.check(lib.mmada_attn_partial(h, 0, st), "attn")
+    Lp = (L + 7) // 8 * 8
+    got = {
+        "xn": tiny_model.debug_buffer(0).view(B, Lp, -1)[:, :L],
+        "q": tiny_model.debug_buffer(1)[:, :, :L],
+        "k": tiny_model.debug_buffer(2)[:, :, :L],
+        "v": tiny_model.debug_buffer(3)[:, :, :, :L].transpose(2, 3),
+        "att": tiny_model.debug_buffer(4).view(B, Lp, -1)[:, :L],
+        "x1": tiny_model.hidden_state(),
+    }
+    got = {k_: v_.clone() for k_, v_ in got.items()}
+    abi.check(lib.mmada_mlp_partial(h, 0, st), "mlp")
+    got["n2"] = tiny_model.debug_buffer(0).view(B, Lp, -1)[:, :L].clone()
+    got["h"] = tiny_model.debug_buffer(5).view(B, Lp, -1)[:, :L].clone()
+    got["x2"] = tiny_model.hidden_state()
+    ref = {"xn": xn, "q": q, "k": k, "v": v, "att": att, "x1": x1, "n2": n2, "h": hmid, "x2": x2}
+    report = {"x0": e_x0}
+    for name in ref:
+        report[name] = _relerr(got[name], ref[name])
+    print("stage errors (max/maxabs, mean/meanabs):", {k_: (f"{a:.2e}", f"{b:.2e}") for k_, (a, b) in report.items()})
+    assert report["x0"][0] == 0.0
+    # the branch deltas, not just the stream: attention and MLP contributions themselves
+    report["d_attn"] = _relerr(got["x1"].float().cpu() - x0.float(), x1.float() - x0.float())
+    report["d_mlp"] = _relerr(got["x2"].float().cpu() - got["x1"].float().cpu(), x2.float() - x1.float())
+    print("branch deltas:", report["d_attn"], report["d_mlp"])
+    for name, (emax, emean) in report.items():
+        # bf16 storage everywhere: a few ulps (2^-8) of the tensor's magnitude; deltas are differences of bf16 values
+        lim_max, lim_mean = (0.25, 0.05) if name.startswith("d_") else (2.0 ** -5, 2.0 ** -8)
+        assert emax < lim_max and emean < lim_mean, f"{name}: {emax:.3e} {emean:.3e}"
+
+
 def test_forward_hidden_and_logits_vs_oracle_and_reference(tiny_model):
     from oracle import llada_oracle
 
@@ -37,9 +111,13 @@ def test_forward_hidden_and_logits_vs_oracle_and_reference(tiny_model):
     ids = torch.from_numpy(z["ids"])
     tiny_model.forward_body(ids.to(DEV))
     hid = tiny_model.hidden_state().cpu().float()[0]
-    ref_hidden = from_bits(z["hidden"])[-1].float()           # reference, last block
+    ref_hidden = from_bits(z["hidden"])[-1].float()           # reference, last block (recorded on the build host)
     ora = llada_oracle.forward_hidden(tiny_sd(), synth.CFG_TINY, ids)[0].float()
-    assert torch.equal(ora, ref_hidden)                        # oracle == reference (pinned)
+    # the oracle is bit-equal to the reference on the host that generated the fixture (tests/test_oracle_golden.py);
+    # another CPU's bf16 GEMM blocking changes the last bits, so here it is a tolerance check
+    o_err = (ora - ref_hidden).abs().max().item() / ref_hidden.abs().max().item()
+    print(f"oracle on this host vs reference fixture: rel err {o_err:.3e}")
+    assert o_err < 2.0 ** -6
     scale = ref_hidden.abs().max().item()
     err = (hid - ref_hidden).abs()
     print(f"hidden: max|err|={err.max():.4g} mean|err|={err.mean():.4g} scale={scale:.4g}")
@@ -150,50 +228,69 @@ def test_generate_stub_trajectory_bit_exact(tiny_model, name):
 
 # --------------------------------------------------------------------------------------------- (iii) teacher-forced e2e
 def test_teacher_forced_tiny_trajectory(tiny_model):
-    """Feed the reference's recorded ids at each step; wherever the GPU step decides differently from the reference,
-    the oracle's own logits must show a near-tie (margin below the bf16 noise floor of the logits)."""
+    """Feed the reference's recorded ids of every conditional call; compare the GPU's per-position decisions
+    (text argmax token + fp64 confidence, image argmax over the CFG-free codebook logits) with the oracle evaluated on
+    the same ids.  A differing argmax must be a near-tie of the oracle's logits; confidences must agree closely.
+    (Which POSITIONS get unmasked is a pure function of these confidences and is checked bit-exactly, on identical
+    inputs, by tests/test_gpu_kernels.py and the stub-trajectory test above.)"""
     from mmada_parallel_amd import abi
-    from mmada_parallel_amd.generators.parallel_generator import get_num_transfer_tokens
     from oracle import llada_oracle
+    from oracle import sampler_oracle as so
 
     z = np.load(os.path.join(GOLDEN, "e2e_tiny.npz"))
-    calls = torch.from_numpy(z["calls"])          # [16, L]: per step cond, (uncond_text, uncond_img) on image steps
+    calls = torch.from_numpy(z["calls"])          # per step: cond, then (uncond_text, uncond_img) on image steps
     job = tiny_job()
     ts, te = job["text_start"], job["text_end"]
     T = te - ts
     text_steps, timesteps = 8, 4
     img_steps = set(torch.linspace(text_steps // 4, text_steps - 1, timesteps).round().int().tolist())
-    k_sched = get_num_transfer_tokens(job["input_ids"][:, ts:te] == synth.MASK, text_steps)[0].tolist()
+    pos = [i for i in range(job["image_start"], job["image_start"] + job["seq_len"] + job["seq_len"] // job["newline_every"])
+           if int(job["input_ids"][0, i]) != synth.NEW_LINE]
     lib, h = tiny_model._lib, tiny_model._handle
     sd, cfg = tiny_sd(), synth.CFG_TINY
-    ci, total, mismatch, worst_margin = 0, 0, 0, 0.0
+    V = tiny_model.vocab
+    ci = 0
+    n_tok = n_tok_bad = n_img = n_img_bad = 0
+    worst_margin, worst_conf = 0.0, 0.0
     for step in range(text_steps):
         ids = calls[ci:ci + 1].clone()
-        nxt_idx = ci + (3 if step in img_steps else 1)
-        # text decision of this step is visible in the next recorded call (uncond_text row for image steps keeps
-        # the text span: the prefix overwrite never reaches it)
-        ref_after = calls[ci + 1] if ci + 1 < calls.shape[0] else None
-        ci = nxt_idx
-        if ref_after is None:
-            break
+        ci += 3 if step in img_steps else 1
         ids_dev = ids.to(DEV)
         tiny_model.forward_body(ids_dev)
         rows = torch.arange(ts, te, dtype=torch.int32, device=DEV)
-        tl = tiny_model.head_rows(rows, 0, tiny_model.vocab)
-        k_dev = torch.tensor([k_sched[step]], dtype=torch.int32, device=DEV)
+        tl = tiny_model.head_rows(rows, 0, V)
+        k_dev = torch.zeros(1, dtype=torch.int32, device=DEV)   # k = 0: statistics only, ids untouched
         scratch = torch.empty(T * 16, dtype=torch.uint8, device=DEV)
-        abi.check(lib.mmada_text_select(h, tl.data_ptr(), None, 1, T, tiny_model.vocab, tiny_model.vocab, ids_dev.data_ptr(),
-                                        ids.shape[1], ts, k_dev.data_ptr(), scratch.data_ptr(), abi.stream_ptr()), "text")
-        got = ids_dev.cpu()[0, ts:te]
-        want = ref_after[ts:te]
-        bad = (got != want).nonzero().flatten().tolist()
-        total += k_sched[step]
-        if bad:
-            ol = llada_oracle.head(sd, cfg, llada_oracle.forward_hidden(sd, cfg, ids)[:, ts:te])[0].float()
-            top2 = ol.topk(2, -1).values
-            for t in bad:
-                mismatch += 1
-                worst_margin = max(worst_margin, (top2[t, 0] - top2[t, 1]).item() / ol[t].std().item())
-    print(f"teacher-forced text decisions: {mismatch} of {total} differ; worst top1-top2 margin = {worst_margin:.4f} sigma")
-    assert mismatch <= max(2, total // 5)
+        abi.check(lib.mmada_text_select(h, tl.data_ptr(), None, 1, T, V, V, ids_dev.data_ptr(), ids.shape[1], ts,
+                                        k_dev.data_ptr(), scratch.data_ptr(), abi.stream_ptr()), "text")
+        conf = scratch[: T * 8].view(torch.float64).cpu()
+        x0 = scratch[T * 8: T * 12].view(torch.int32).cpu()
+        ol = llada_oracle.head(sd, cfg, llada_oracle.forward_hidden(sd, cfg, ids)[:, ts:te])   # [1,T,V] bf16
+        _, conf_o, x0_o = so.text_select(ol, None, ids, ts, [0])
+        masked = torch.isfinite(conf_o[0])
+        assert torch.equal(torch.isfinite(conf), masked)
+        olf = ol[0].float()
+        for t in masked.nonzero().flatten().tolist():
+            n_tok += 1
+            if int(x0[t]) != int(x0_o[0, t]):
+                n_tok_bad += 1
+                top2 = olf[t].topk(2).values
+                worst_margin = max(worst_margin, ((top2[0] - top2[1]) / olf[t].std()).item())
+            else:
+                worst_conf = max(worst_conf, abs(conf[t].item() / conf_o[0, t].item() - 1.0))
+        if step in img_steps:
+            irows = torch.tensor(pos, dtype=torch.int32, device=DEV)
+            il = tiny_model.head_rows(irows, synth.TEXT_VOCAB, synth.TEXT_VOCAB + synth.CODEBOOK).cpu().float()
+            oil = llada_oracle.head(sd, cfg, llada_oracle.forward_hidden(sd, cfg, ids)[:, pos], synth.TEXT_VOCAB,
+                                    synth.TEXT_VOCAB + synth.CODEBOOK)[0].float()
+            for n in range(len(pos)):
+                n_img += 1
+                if int(il[n].argmax()) != int(oil[n].argmax()):
+                    n_img_bad += 1
+                    top2 = oil[n].topk(2).values
+                    worst_margin = max(worst_margin, ((top2[0] - top2[1]) / oil[n].std()).item())
+    print(f"teacher-forced: text argmax {n_tok_bad}/{n_tok} differ, image argmax {n_img_bad}/{n_img} differ, "
+          f"worst oracle top1-top2 margin at a disagreement = {worst_margin:.4f} sigma, worst confidence rel diff = {worst_conf:.3e}")
     assert worst_margin < 0.05, "a disagreement with a clear oracle margin is a kernel bug, not a near-tie"
+    assert worst_conf < 0.05
+    assert n_tok_bad <= n_tok // 4 and n_img_bad <= n_img // 4
