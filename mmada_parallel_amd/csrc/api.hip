@@ -431,6 +431,14 @@ int mmada_gemm_bt(const void* A, const void* W, void* C, int M, int N, int K, vo
     return launch_gemm(EPI_STORE, g, (hipStream_t)stream);
 }
 
+int mmada_gemm_variant(int variant, const void* A, const void* W, void* C, int M, int N, int K, void* stream) {
+    if (!A || !W || !C) return mm_fail("mmada_gemm_variant: null argument");
+    GemmArgs g{};
+    g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.C = (bf16_t*)C;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N;
+    return launch_gemm_variant(variant, g, (hipStream_t)stream);
+}
+
 int mmada_rmsnorm(const void* x, const void* w, void* out, int rows, int d, float eps, void* stream) {
     if (!x || !w || !out) return mm_fail("mmada_rmsnorm: null argument");
     return launch_rmsnorm((const bf16_t*)x, (const bf16_t*)w, (bf16_t*)out, rows, d, eps, (hipStream_t)stream);

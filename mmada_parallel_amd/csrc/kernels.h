@@ -26,6 +26,7 @@ struct GemmArgs {
 };
 
 int launch_gemm(int epi, const GemmArgs& g, hipStream_t s);
+int launch_gemm_variant(int variant, const GemmArgs& g, hipStream_t s);  // gemm_var.hip
 
 // elementwise.hip
 int launch_embed(const int64_t* ids, const bf16_t* wte, bf16_t* x, int B, int L, int Lp, int d, int vocab, hipStream_t s);

@@ -1,0 +1,68 @@
+#!/usr/bin/env python
+"""Time the GEMM tile/pipeline variants (csrc/gemm_var.hip) on the four projection shapes of the 8B block.
+
+    python tools/gemm_sweep.py [--variants 0,1,2] [--m 2438,4876]
+Random bf16 operands (zero-filled operands clock ~20 % higher: never bench on zeros).  Interleaved rounds, median.
+"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+from mmada_parallel_amd import abi  # noqa: E402
+
+SHAPES = {"qkv": (12288, 4096), "o": (4096, 4096), "gateup": (24576, 4096), "down": (4096, 12288)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--variants", default="0,1,2,3,4,5,6,7,8,9,10,11")
+    ap.add_argument("--m", default="2438,4876")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--check", action="store_true")
+    args = ap.parse_args()
+    lib = abi.lib()
+    dev = "cuda:0"
+    variants = [int(v) for v in args.variants.split(",")]
+    st = torch.cuda.current_stream().cuda_stream
+    print(f"{'shape':8s} {'M':>5s} " + " ".join(f"v{v:<6d}" for v in variants) + "   (TFLOP/s, median)")
+    for M in [int(m) for m in args.m.split(",")]:
+        for name, (N, K) in SHAPES.items():
+            A = torch.randn(M, K, device=dev).to(torch.bfloat16)
+            W = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
+            C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            res = {v: [] for v in variants}
+            ok = {}
+            for v in variants:
+                if lib.mmada_gemm_variant(v, A.data_ptr(), W.data_ptr(), C.data_ptr(), M, N, K, st) != 0:
+                    res[v] = None
+                    continue
+                if args.check:
+                    ref = A[:256].float() @ W.float().t()
+                    ok[v] = bool(((C[:256].float() - ref).abs() <= 2.0 ** -8 * ref.abs() + 1e-3 * ref.abs().max()).all())
+            for _ in range(args.rounds):
+                for v in variants:
+                    if res[v] is None:
+                        continue
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    for _ in range(5):
+                        lib.mmada_gemm_variant(v, A.data_ptr(), W.data_ptr(), C.data_ptr(), M, N, K, st)
+                    e1.record()
+                    e1.synchronize()
+                    res[v].append(e0.elapsed_time(e1) / 5)
+            cells = []
+            for v in variants:
+                if res[v] is None:
+                    cells.append("  n/a  ")
+                else:
+                    ms = sorted(res[v])[len(res[v]) // 2]
+                    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+                    cells.append(f"{tf:6.0f}{'' if ok.get(v, True) else '!'} ")
+            print(f"{name:8s} {M:5d} " + " ".join(cells))
+
+
+if __name__ == "__main__":
+    main()
