@@ -11,7 +11,9 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import bits
+import os
+
+from helpers import ROOT, bits
 from mmada_parallel_amd import abi, synth
 
 pytestmark = pytest.mark.gpu
@@ -40,8 +42,30 @@ def handle():
 
 
 # ---------------------------------------------------------------------------------------------------------------- GEMM
+def test_gemm_every_row_tile_height():
+    """Each BM configuration of the production kernel (forced through MMADA_GEMM_BM in a fresh process)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import torch, sys; sys.path.insert(0, %r)\n"
+        "from mmada_parallel_amd import abi\n"
+        "torch.manual_seed(0)\n"
+        "for (M, N, K) in [(517, 768, 192), (2438, 4096, 1024)]:\n"
+        "    A = torch.randn(M, K, device='cuda').to(torch.bfloat16); W = (torch.randn(N, K, device='cuda') * 0.05).to(torch.bfloat16)\n"
+        "    C = torch.full((M, N), float('nan'), dtype=torch.bfloat16, device='cuda')\n"
+        "    abi.check(abi.lib().mmada_gemm_bt(A.data_ptr(), W.data_ptr(), C.data_ptr(), M, N, K, abi.stream_ptr()))\n"
+        "    ref = A.float() @ W.float().t(); err = (C.float() - ref).abs()\n"
+        "    assert (err <= 2.0 ** -8 * ref.abs() + 1e-3 * ref.abs().max()).all(), err.max().item()\n"
+        "print('ok')\n" % ROOT)
+    for bm in (128, 160, 192, 224, 256):
+        env = dict(os.environ, MMADA_GEMM_BM=str(bm))
+        out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "ok" in out.stdout, f"BM={bm}: {out.stderr[-800:]}"
+
+
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 384, 256), (77, 200, 128), (1000, 8192, 256),
-                                   (2438, 4096, 4096), (2440, 12288, 4096)])
+                                   (2438, 4096, 4096), (2440, 12288, 4096), (4876, 4096, 12288)])
 def test_gemm_bt(M, N, K):
     torch.manual_seed(M + N + K)
     A = torch.randn(M, K, device=DEV).to(torch.bfloat16)

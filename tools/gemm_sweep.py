@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--m", default="2438,4876")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--cold", type=int, default=6, help="rotate over this many operand copies (defeats the 256 MB MALL)")
     args = ap.parse_args()
     lib = abi.lib()
     dev = "cuda:0"
@@ -33,6 +34,8 @@ def main():
             A = torch.randn(M, K, device=dev).to(torch.bfloat16)
             W = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
             C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+            As = [A] + [A.clone() for _ in range(args.cold - 1)]
+            Ws = [W] + [W.clone() for _ in range(args.cold - 1)]
             res = {v: [] for v in variants}
             ok = {}
             for v in variants:
@@ -48,11 +51,13 @@ def main():
                         continue
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    for _ in range(5):
-                        lib.mmada_gemm_variant(v, A.data_ptr(), W.data_ptr(), C.data_ptr(), M, N, K, st)
+                    nrep = max(5, args.cold)
+                    for i in range(nrep):
+                        lib.mmada_gemm_variant(v, As[i % args.cold].data_ptr(), Ws[i % args.cold].data_ptr(), C.data_ptr(),
+                                               M, N, K, st)
                     e1.record()
                     e1.synchronize()
-                    res[v].append(e0.elapsed_time(e1) / 5)
+                    res[v].append(e0.elapsed_time(e1) / nrep)
             cells = []
             for v in variants:
                 if res[v] is None:
