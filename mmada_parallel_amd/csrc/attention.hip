@@ -4,16 +4,18 @@
 // (model/modeling_llada.py:672-679 via :731-738; the attention-bias machinery around it is dead code).
 //
 // Layout contract (produced by the QKV GEMM epilogue): q [B,Hq,Lkv,128], k [B,Hkv,Lkv,128] row-major and V stored
-// K-major as vT [B,Hkv,128,Lkv], so both MFMA operands of both products are contiguous along the contraction.
+// K-major as vT [B,Hkv,128,Lkv] with the keys of every 16-key group stored in the order [0-3, 8-11, 4-7, 12-15]
+// (vt_key_pos in common.h), so both MFMA operands of both products are one contiguous 16-byte read.
 //
-// One workgroup = 4 waves = 128 query rows; one wave owns 32 query rows and the whole 512-deep softmax state.
+// One workgroup = 4 waves = 128 query rows; one wave owns 32 query rows and the whole softmax state.
 //   S^T = K·Q^T   : v_mfma_f32_32x32x16_bf16, A = K tile rows (LDS), B = Q rows (registers) -> each lane holds
 //                   16 scores of ONE query (its column), so row max/sum are in-lane + one lane^32 exchange.
-//   O^T = V^T·P^T : A = vT tile rows (LDS, 2 x ds_read_b64), B = P straight from the S accumulator registers —
-//                   the k-slot order of the two operands is chosen to match the accumulator layout
-//                   (key = (r&3) + 8*(r>>2) + 4*(lane>>5)), so P never moves between lanes.
-// K/V tiles (64 keys) are double-buffered in LDS through registers (issue-early / write-late), K rows XOR-swizzled
-// per 16-B chunk and vT rows per 8-B chunk so ds_read_b128 / ds_read_b64 are conflict-free.
+//   O^T = V^T·P^T : A = vT tile rows (LDS), B = P straight from the S accumulator registers — the key order of the
+//                   stored vT rows is exactly the accumulator's key order (key = (r&3) + 8*(r>>2) + 4*(lane>>5)),
+//                   so P never moves between lanes and V needs no transpose read.
+// K/V tiles (64 keys) arrive by LDS-DMA (global_load_lds_dwordx4) into a 2-stage ring, one barrier per tile; the
+// 16-B-chunk XOR swizzle is applied to the DMA source address and to the ds_read_b128 address (conflict-free).
+// The O rescale is skipped while the running max grows by less than 2^DEFER_LOG2 (P stays <= 2^DEFER_LOG2).
 #include "kernels.h"
 
 namespace {
@@ -22,6 +24,10 @@ constexpr int QB = 128;  // query rows per workgroup
 constexpr int KB = 64;   // keys per tile
 constexpr int TILE_BYTES = KB * 128 * 2;  // 16 KiB (K tile == vT tile)
 constexpr int ATT_LDS = 4 * TILE_BYTES;   // 2 stages x (K + vT)
+constexpr float DEFER_LOG2 = 4.0f;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
 struct AttnArgs {
     const bf16_t* q;
@@ -32,11 +38,10 @@ struct AttnArgs {
     float scale_log2e;
 };
 
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hi = lane >> 5;
     const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const int hkv = h / (a.Hq / a.Hkv);
@@ -55,43 +60,37 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;
+    float m_run = -1e30f, l_run = 0.f;  // m_run in scaled log2 units
 
-    u32x4 kreg[4], vreg[4];
-    // per-thread 32-bit element offsets inside a tile; the tile base stays wave-uniform (SGPR base + VGPR offset)
-    const int koff = (tid >> 4) * 128 + (tid & 15) * 8;
-    const int voff = (tid >> 3) * a.Lkv + (tid & 7) * 8;
-    auto load_regs = [&](int kt) {
+    // LDS-DMA sources: wave w moves K pieces 4w..4w+3 (4 rows x 256 B each) and vT pieces 4w..4w+3 (8 rows x 128 B)
+    int koff[4], voff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int kr = (wave * 4 + i) * 4 + (lane >> 4);
+        koff[i] = kr * 128 + (((lane & 15) ^ (kr & 15)) << 3);
+        const int d = (wave * 4 + i) * 8 + (lane >> 3);
+        voff[i] = d * a.Lkv + (((lane & 7) ^ ((d >> 1) & 7)) << 3);
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * 2 * TILE_BYTES + wave * 4096;
         const bf16_t* kb = Kp + (size_t)kt * KB * 128;
         const bf16_t* vb = Vp + kt * KB;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            kreg[i] = *(const u32x4*)(kb + koff + i * 16 * 128);
-            vreg[i] = *(const u32x4*)(vb + voff + i * 32 * a.Lkv);
-        }
-    };
-    auto write_lds = [&](int buf) {
-        char* Kt = smem + buf * 2 * TILE_BYTES;
-        char* Vt = Kt + TILE_BYTES;
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(kb + koff[i]), (lptr_t)(base + i * 1024), 16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int id = i * 256 + tid;
-            const int kr = id >> 4, kc = id & 15;
-            *(u32x4*)(Kt + kr * 256 + ((kc ^ (kr & 15)) << 4)) = kreg[i];
-            const int d = id >> 3, c8 = (id & 7) * 2, sw = (d >> 1) & 15;
-            *(u32x2*)(Vt + d * 128 + ((c8 ^ sw) << 3)) = u32x2{vreg[i][0], vreg[i][1]};
-            *(u32x2*)(Vt + d * 128 + (((c8 + 1) ^ sw) << 3)) = u32x2{vreg[i][2], vreg[i][3]};
-        }
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(vb + voff[i]), (lptr_t)(base + TILE_BYTES + i * 1024), 16, 0, 0);
     };
 
     const int nkt = (a.L + KB - 1) / KB;
-    load_regs(0);
-    write_lds(0);
-    __syncthreads();
+    const int ksw = ql & 15, vsw = (ql >> 1) & 7;
+    stage(0, 0);
 
     for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const char* Kt = smem + cur * 2 * TILE_BYTES;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 1 < nkt) stage((kt + 1) & 1, kt + 1);
+        const char* Kt = smem + (kt & 1) * 2 * TILE_BYTES;
         const char* Vt = Kt + TILE_BYTES;
 
         // ---- S^T = K · Q^T for keys [0,32) and [32,64) of the tile ----
@@ -100,7 +99,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const int ch = ((2 * s + hi) ^ (ql & 15)) << 4;
+            const int ch = ((2 * s + hi) ^ ksw) << 4;
             const bf16x8 ka0 = *(const bf16x8*)(Kt + ql * 256 + ch);
             const bf16x8 ka1 = *(const bf16x8*)(Kt + (32 + ql) * 256 + ch);
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qf[s], s0, 0, 0, 0);
@@ -116,27 +115,29 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                 if (key + 32 >= a.L) s1[r] = -INFINITY;
             }
         }
-        // ---- online softmax (fp32); lane and lane^32 share a query ----
+        // ---- online softmax (fp32, log2 domain); lane and lane^32 share a query ----
         float mx = fmaxf(s0[0], s1[0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * a.scale_log2e);
-        const float mc = m_new * a.scale_log2e;
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2e;
+        if (!__all(mx - m_run <= DEFER_LOG2)) {  // wave-uniform: rescale only when some row's max really grew
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+            m_run = m_new;
+        }
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(s0[r] * a.scale_log2e - mc);
-            s1[r] = __builtin_amdgcn_exp2f(s1[r] * a.scale_log2e - mc);
+            s0[r] = __builtin_amdgcn_exp2f(s0[r] * a.scale_log2e - m_run);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r] * a.scale_log2e - m_run);
             psum += s0[r] + s1[r];
         }
-        l_run = l_run * alpha + psum;
-        m_run = m_new;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        l_run += psum;
 
         // P -> bf16 B-operand fragments: pb[t][s2] = P[q][keys of accumulator regs 8*s2 .. 8*s2+7 of tile t]
         bf16x8 pb[2][2];
@@ -148,33 +149,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                 pb[1][s2][j] = (__bf16)s1[8 * s2 + j];
             }
 
-        // next tile: global -> registers now (in flight under the PV MFMAs), registers -> LDS after them.
-        // Issued here rather than at the top of the iteration so the 32 staging VGPRs are never live together
-        // with the 32 score registers (keeps the kernel at 2 waves/SIMD without spills).
-        __builtin_amdgcn_sched_barrier(0);
-        if (kt + 1 < nkt) load_regs(kt + 1);
-
         // ---- O^T += V^T · P^T ----
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
-            // row d = db*32 + ql; its swizzle ((d>>1)&15) does not depend on db, so the 8 chunk addresses are
-            // shared by the four d-blocks up to an immediate offset
-            const char* vrow = Vt + ql * 128 + db * 32 * 128;
-            const int sw = (ql >> 1) & 15;
+            const char* vrow = Vt + (db * 32 + ql) * 128;  // swizzle of row db*32+ql does not depend on db
 #pragma unroll
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const int ca = 8 * t + 4 * s2 + hi;
-                    const bf16x4 lo = *(const bf16x4*)(vrow + ((ca ^ sw) << 3));
-                    const bf16x4 hi4 = *(const bf16x4*)(vrow + (((ca + 2) ^ sw) << 3));
-                    const bf16x8 va = __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7);
+                    const bf16x8 va = *(const bf16x8*)(vrow + (((4 * t + 2 * s2 + hi) ^ vsw) << 4));
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[t][s2], o[db], 0, 0, 0);
                 }
         }
-
-        if (kt + 1 < nkt) write_lds(cur ^ 1);
-        __syncthreads();
     }
 
     // ---- normalise and store: lane holds O[q_row][d = db*32 + 8g + 4hi + j] ----

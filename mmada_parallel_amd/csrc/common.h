@@ -51,6 +51,14 @@ MM_DEVICE int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
+// Position of key l inside the K-major V buffer: the four 4-key chunks of every 16-key group are stored in the
+// order [0, 2, 1, 3], which is the key order of a 32x32 MFMA accumulator column (key = (r&3) + 8*(r>>2) + 4*hi),
+// so the attention PV operand is one 16-byte read (attention.hip).
+MM_DEVICE int vt_key_pos(int l) {
+    const int c = (l >> 2) & 3;
+    return (l & ~12) | ((c & 1) << 3) | ((c >> 1) << 2);
+}
+
 #define MM_CHECK_HIP(expr)                                                                 \
     do {                                                                                   \
         hipError_t _e = (expr);                                                            \

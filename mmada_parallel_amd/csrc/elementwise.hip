@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void transpose_v_kernel(const bf16_t* __restri
     __syncthreads();
     for (int e = threadIdx.x; e < 64 * 64; e += 256) {
         const int r = e >> 6, c = e & 63;  // r: d, c: l
-        if (l0 + c < Lkv) vT[((size_t)bh * 128 + d0 + r) * Lkv + l0 + c] = tile[c][r];
+        if (l0 + c < Lkv) vT[((size_t)bh * 128 + d0 + r) * Lkv + vt_key_pos(l0 + c)] = tile[c][r];
     }
 }
 

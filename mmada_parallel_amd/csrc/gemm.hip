@@ -221,7 +221,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bt_kernel(GemmArgs g) {
                     u32x2 pk;
                     pk[0] = pack_bf2(acc[mi][ni][0], acc[mi][ni][1]);
                     pk[1] = pack_bf2(acc[mi][ni][2], acc[mi][ni][3]);
-                    *(u32x2*)(g.vT + ((size_t)(b * g.Hkv + hv) * 128 + d) * g.Lkv + l0) = pk;
+                    *(u32x2*)(g.vT + ((size_t)(b * g.Hkv + hv) * 128 + d) * g.Lkv + vt_key_pos(l0)) = pk;
                 }
             }
         }

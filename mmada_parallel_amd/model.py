@@ -214,7 +214,10 @@ class LLaDAForMultiModalGeneration:
         for v in shape:
             n *= v
         off = p.value - self._ws.data_ptr()
-        return self._ws[off:off + n].view(torch.bfloat16).view(*shape)
+        t = self._ws[off:off + n].view(torch.bfloat16).view(*shape)
+        if which == 3:  # undo the [0,2,1,3] chunk order of every 16-key group (csrc/common.h vt_key_pos)
+            t = t.reshape(B, hkv, 128, lkv.value // 16, 4, 4)[..., [0, 2, 1, 3], :].reshape(B, hkv, 128, lkv.value)
+        return t
 
     def forward(self, input_ids=None, labels=None, infer=False, use_cache=False, **_):
         if not infer or labels is not None:
