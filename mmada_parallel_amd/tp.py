@@ -1,0 +1,48 @@
+"""Tensor-parallel shard plan of one LLaDA block (the slicing the bind-time repack kernels implement,
+csrc/elementwise.hip pack_qkv/pack_gate_up/pack_cols) as plain index arithmetic, so it can be checked on CPU.
+
+Megatron-style: q/k/v and ff_proj/up_proj are column-parallel (output-feature slices: whole heads / MLP columns),
+attn_out and ff_out are row-parallel (input-feature slices).  Each rank produces a partial sum of the two
+row-parallel outputs; rank 0 additionally adds the residual, so  all_reduce(sum)  of the per-rank buffers IS the new
+residual stream (reference block: model/modeling_llada.py:906-972).
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+
+def head_range(n_heads: int, rank: int, size: int) -> Tuple[int, int]:
+    if n_heads % size:
+        raise ValueError(f"{n_heads} heads not divisible by tp_size {size}")
+    per = n_heads // size
+    return rank * per, (rank + 1) * per
+
+
+def layer_shards(cfg: dict, rank: int, size: int) -> Dict[str, Tuple[int, slice]]:
+    """name -> (dim, slice) of the checkpoint tensor `blocks.{i}.<name>.weight` kept by `rank`."""
+    hd = cfg["d_model"] // cfg["n_heads"]
+    n_kv = cfg.get("n_kv_heads") or cfg["n_heads"]
+    F = cfg["mlp_hidden_size"]
+    if F % size:
+        raise ValueError("mlp_hidden_size not divisible by tp_size")
+    q0, q1 = head_range(cfg["n_heads"], rank, size)
+    k0, k1 = head_range(n_kv, rank, size)
+    f0, f1 = rank * (F // size), (rank + 1) * (F // size)
+    return {
+        "q_proj": (0, slice(q0 * hd, q1 * hd)), "k_proj": (0, slice(k0 * hd, k1 * hd)),
+        "v_proj": (0, slice(k0 * hd, k1 * hd)), "attn_out": (1, slice(q0 * hd, q1 * hd)),
+        "ff_proj": (0, slice(f0, f1)), "up_proj": (0, slice(f0, f1)), "ff_out": (1, slice(f0, f1)),
+    }
+
+
+def shard_layer_weights(weights: dict, cfg: dict, rank: int, size: int) -> dict:
+    """Apply layer_shards to a dict of full block tensors (norm weights are replicated)."""
+    plan = layer_shards(cfg, rank, size)
+    out = {}
+    for name, w in weights.items():
+        if name in plan:
+            dim, sl = plan[name]
+            out[name] = w[sl] if dim == 0 else w[:, sl]
+        else:
+            out[name] = w
+    return out

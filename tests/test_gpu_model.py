@@ -294,3 +294,45 @@ def test_teacher_forced_tiny_trajectory(tiny_model):
     assert worst_margin < 0.05, "a disagreement with a clear oracle margin is a kernel bug, not a near-tie"
     assert worst_conf < 0.05
     assert n_tok_bad <= n_tok // 4 and n_img_bad <= n_img // 4
+
+
+# ------------------------------------------------------------------------------------------------- tensor parallel
+@pytest.mark.parametrize("tp", [2])
+def test_tensor_parallel_slices_on_one_gpu(tiny_model, tp):
+    """TP=2 emulated on one GPU: two handles (tp_rank 0/1) from the same checkpoint, the all-reduce replaced by an
+    explicit sum of their partial residual streams.  Must agree with the TP=1 forward up to bf16 re-association."""
+    from mmada_parallel_amd import LLaDAForMultiModalGeneration, abi
+
+    cfg = synth.full_config(synth.CFG_TINY)
+    ranks = [LLaDAForMultiModalGeneration.from_state_dict(cfg, tiny_sd(), device=DEV, tp_rank=r, tp_size=tp)
+             for r in range(tp)]
+    job = tiny_job()
+    ids = job["input_ids"].repeat(2, 1).to(DEV)
+    ids[1, :6] = torch.arange(50, 56, device=DEV)
+    B, L = ids.shape
+    st = abi.stream_ptr()
+    for m in ranks:
+        m._ensure_ws(B, L)
+        m._shape = (B, L)
+        abi.check(m._lib.mmada_embed(m._handle, ids.data_ptr(), B, L, st), "embed")
+    for layer in range(cfg["n_layers"]):
+        for seg in ("mmada_attn_partial", "mmada_mlp_partial"):
+            for m in ranks:
+                abi.check(getattr(m._lib, seg)(m._handle, layer, st), seg)
+            views = [m._stream_view() for m in ranks]
+            total = views[0].float()
+            for v in views[1:]:
+                total = total + v.float()
+            total = total.to(torch.bfloat16)
+            for v in views:
+                v.copy_(total)
+    got = ranks[0].hidden_state().float().cpu()
+    tiny_model.forward_body(ids)
+    ref = tiny_model.hidden_state().float().cpu()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    print(f"TP={tp} vs TP=1 hidden rel err {err:.3e}")
+    assert err < 2.0 ** -5   # a few bf16 ulps of the stream: the two partial sums are rounded before they are added
+    rows = torch.arange(B * L, dtype=torch.int32, device=DEV)
+    lg = ranks[0].head_rows(rows, synth.TEXT_VOCAB, synth.TEXT_VOCAB + 512).float().cpu()
+    lr = tiny_model.head_rows(rows, synth.TEXT_VOCAB, synth.TEXT_VOCAB + 512).float().cpu()
+    assert (lg - lr).abs().max().item() < 2.0 ** -5 * lr.abs().max().item()
