@@ -90,11 +90,13 @@ def main():
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run: one rank per GPU over RCCL
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from mmada_parallel_amd import LLaDAForMultiModalGeneration, abi, generate_ti2ti, synth
 
@@ -121,7 +123,7 @@ def main():
                               uncon_image=job["uncon_image"])
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -137,7 +139,7 @@ def main():
     dt = time.perf_counter() - t0
     cnt, ms, fl = (C.c_int32 * 5)(), (C.c_double * 5)(), (C.c_double * 5)()
     abi.check(lib.mmada_profile_end(h, cnt, ms, fl), "profile_end")
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
@@ -173,7 +175,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, job)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -55,6 +55,10 @@ typedef struct mmada_cfg {
  * the library; pass the torch-computed vector to reproduce the reference's fp32 table bit-for-bit. */
 int mmada_create(const mmada_cfg* cfg, const float* inv_freq_host, mmada_handle** out);
 int mmada_destroy(mmada_handle* h);
+/* Second activation context over the SAME bound weights (borrowed from `h`, which must outlive the clone): lets a
+ * caller keep two micro-batches in flight, e.g. to overlap one micro-batch's tensor-parallel all-reduce with the
+ * other's GEMMs.  The clone needs its own workspace; bind_* on a clone is an error. */
+int mmada_clone_shared(mmada_handle* h, mmada_handle** out);
 const char* mmada_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
 int mmada_abi_version(void);

@@ -30,6 +30,7 @@ class MmadaCfg(C.Structure):
 SIGNATURES = {
     "mmada_create": (c_int, [C.POINTER(MmadaCfg), C.POINTER(C.c_float), C.POINTER(c_void_p)]),
     "mmada_destroy": (c_int, [c_void_p]),
+    "mmada_clone_shared": (c_int, [c_void_p, C.POINTER(c_void_p)]),
     "mmada_last_error": (C.c_char_p, []),
     "mmada_abi_version": (c_int, []),
     "mmada_bind_globals": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -41,6 +41,7 @@ struct mmada_handle {
     const bf16_t* ln_f = nullptr;
     const bf16_t* lm_head = nullptr;
     std::vector<LayerWeights> layers;
+    bool owns_weights = true;  // false for mmada_clone_shared handles
     // workspace
     char* ws = nullptr;
     size_t ws_bytes = 0;
@@ -150,8 +151,24 @@ int mmada_create(const mmada_cfg* cfg, const float* inv_freq_host, mmada_handle*
     return 0;
 }
 
+int mmada_clone_shared(mmada_handle* h, mmada_handle** out) {
+    if (!h || !out) return mm_fail("mmada_clone_shared: null argument");
+    mmada_handle* c = new mmada_handle();
+    c->cfg = h->cfg;
+    c->hq_l = h->hq_l; c->hkv_l = h->hkv_l; c->f_l = h->f_l;
+    c->rope_cos = h->rope_cos; c->rope_sin = h->rope_sin;
+    c->wte = h->wte; c->ln_f = h->ln_f; c->lm_head = h->lm_head;
+    c->layers = h->layers;  // pointer copies
+    c->owns_weights = false;
+    *out = c;
+    return 0;
+}
+
 int mmada_destroy(mmada_handle* h) {
     if (!h) return 0;
+    for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    for (auto& e : h->prof_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    if (!h->owns_weights) { delete h; return 0; }
     for (auto& lw : h->layers) {
         (void)hipFree(lw.wqkv); (void)hipFree(lw.wo); (void)hipFree(lw.wgu);
         (void)hipFree(lw.wdown); (void)hipFree(lw.attn_norm); (void)hipFree(lw.ff_norm);
@@ -174,6 +191,7 @@ int mmada_bind_layer(mmada_handle* h, int layer, const void* attn_norm, const vo
                      const void* k_proj, const void* v_proj, const void* attn_out, const void* ff_proj,
                      const void* up_proj, const void* ff_out, void* stream) {
     if (!h) return mm_fail("mmada_bind_layer: null handle");
+    if (!h->owns_weights) return mm_fail("mmada_bind_layer: handle is a shared clone");
     if (layer < 0 || layer >= h->cfg.n_layers) return mm_fail("mmada_bind_layer: layer %d out of range", layer);
     if (!attn_norm || !ff_norm || !q_proj || !k_proj || !v_proj || !attn_out || !ff_proj || !up_proj || !ff_out)
         return mm_fail("mmada_bind_layer: null weight pointer");

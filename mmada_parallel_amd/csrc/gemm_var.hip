@@ -240,6 +240,312 @@ int launch_var32(const GemmArgs& g, hipStream_t s) {
     return 0;
 }
 
+// "Big wave" structure: 256x256 block, 4 waves (one per SIMD, 512-register budget), each wave a 128x128 sub-tile
+// (8x8 fragments, 256 accumulator registers); K streamed in 32-deep slices through a ring of RING LDS buffers with
+// counted vmcnt; the fragments of slice t+1 are read into a second register set while slice t is multiplied.
+template <int RING, bool PREFETCH>
+__global__ __launch_bounds__(256, 1) void gemm_big_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 32, RB = 64, CPR = 4, RPP = 16, NW = 4;
+    constexpr int A_BYTES = BM * RB, STAGE_BYTES = (BM + BN) * RB;  // 32 KiB per slice
+    constexpr int PA = BM / RPP / NW, PB = BN / RPP / NW;           // 4 + 4 pieces per wave per slice
+    constexpr int P = PA + PB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    constexpr int GN = 4;
+    const int gsize = GN * ntm;
+    const int grp = id / gsize, rem = id - grp * gsize;
+    const int gn = min(GN, ntn - grp * GN);
+    const int mt = rem / gn, nt = grp * GN + (rem - (rem / gn) * gn);
+    const int m0 = mt * BM, n0 = nt * BN;
+    auto swz = [](int row) { return (row >> 2) & 3; };
+    const bf16_t* asrc[PA];
+    const bf16_t* wsrc[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int row = (wave * PA + i) * RPP + lane / CPR;
+        asrc[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + ((lane % CPR) ^ swz(row)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int row = (wave * PB + i) * RPP + lane / CPR;
+        wsrc[i] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw + ((lane % CPR) ^ swz(row)) * 8;
+    }
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto stage = [&](int kt) {
+        char* base = smem + (kt % RING) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BK), (lptr_t)(base + (wave * PA + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kt * BK), (lptr_t)(base + A_BYTES + (wave * PB + i) * 1024),
+                                             16, 0, 0);
+    };
+    const int frow = lane & 15, fq = lane >> 4;
+    int aoff[8], boff[8];  // byte offsets of this lane's fragments inside a slice
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int ra = wm * 128 + i * 16 + frow, rb = wn * 128 + i * 16 + frow;
+        aoff[i] = ra * RB + ((fq ^ swz(ra)) << 4);
+        boff[i] = A_BYTES + rb * RB + ((fq ^ swz(rb)) << 4);
+    }
+    auto load_frags = [&](int kt, bf16x8 (&a)[8], bf16x8 (&b)[8]) {
+        const char* base = smem + (kt % RING) * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a[i] = *(const bf16x8*)(base + aoff[i]);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) b[i] = *(const bf16x8*)(base + boff[i]);
+    };
+    auto mma = [&](bf16x8 (&a)[8], bf16x8 (&b)[8]) {
+#pragma unroll
+        for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni)
+                acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+    };
+    const int nk = g.K / BK;
+    constexpr int AHEAD = RING - 1;  // slices in flight beyond the one being multiplied
+#pragma unroll
+    for (int s = 0; s < AHEAD; ++s)
+        if (s < nk) stage(s);
+    bf16x8 a0[8], b0[8], a1[8], b1[8];
+    if constexpr (PREFETCH) {
+        // certify slice 0, read its fragments
+        if (AHEAD - 1 < nk) wait_vm_lgkm<(AHEAD - 1) * P>(); else wait_vm_lgkm<0>();
+        load_frags(0, a0, b0);
+        for (int kt = 0; kt < nk; kt += 2) {
+            // step kt: slices <= kt+1 landed (own pieces), then everyone's; ring slot of slice kt-1 is free
+            if (kt + AHEAD - 1 < nk) wait_vm_lgkm<(AHEAD - 2) * P>(); else wait_vm_lgkm<0>();
+            if (kt + AHEAD < nk) stage(kt + AHEAD);
+            if (kt + 1 < nk) load_frags(kt + 1, a1, b1);
+            mma(a0, b0);
+            if (kt + 1 >= nk) break;
+            if (kt + AHEAD < nk) wait_vm_lgkm<(AHEAD - 2) * P>(); else wait_vm_lgkm<0>();
+            if (kt + 1 + AHEAD < nk) stage(kt + 1 + AHEAD);
+            if (kt + 2 < nk) load_frags(kt + 2, a0, b0);
+            mma(a1, b1);
+        }
+    } else {
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + AHEAD - 1 < nk) wait_vm_lgkm<(AHEAD - 1) * P>(); else wait_vm_lgkm<0>();
+            if (kt + AHEAD < nk) stage(kt + AHEAD);
+            load_frags(kt, a0, b0);
+            mma(a0, b0);
+        }
+    }
+    const int mrow0 = m0 + wm * 128 + fq * 4, ncol0 = n0 + wn * 128 + frow;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mrow0 + mi * 16 + r;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < 8; ++ni) {
+                const int n = ncol0 + ni * 16;
+                if (n < g.N) g.C[(size_t)m * g.ldc + n] = f2bf(acc[mi][ni][r]);
+            }
+        }
+}
+
+// "Ping-pong" structure: 256x256x64 tile, 8 waves = two groups of four (one wave of each group per SIMD).  Every
+// K-tile is 8 barrier-separated phases per wave, alternating R (LDS fragment reads + LDS-DMA issue for the next
+// K-tile) and C (16 MFMAs on one 64x32 quadrant of the wave's 128x64 sub-tile).  Group B runs one phase behind
+// group A, so while one wave of a SIMD streams MFMAs its partner does its LDS traffic.
+#define PP_BARRIER()                                   \
+    do {                                               \
+        __builtin_amdgcn_sched_barrier(0);             \
+        asm volatile("s_barrier" ::: "memory");        \
+        __builtin_amdgcn_sched_barrier(0);             \
+    } while (0)
+#define PP_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define PP_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+
+template <bool SETPRIO, int GRPMODE>
+__global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 64, A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // 0: group A, 1: group B (one phase behind); the two groups must share SIMDs pairwise — which wave-id bit
+    // separates SIMD partners is a dispatch detail, so it is a measured choice (GRPMODE)
+    const int grp = GRPMODE == 0 ? (wave >> 2) : GRPMODE == 1 ? (wave & 1) : ((wave >> 1) & 1);
+    const int wn = GRPMODE == 0 ? (wave & 3) : GRPMODE == 1 ? (wave >> 1) : ((wave & 1) | ((wave >> 2) << 1));
+    const int wm = grp;  // wave tile: rows wm*128.., cols wn*64..
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    constexpr int GN = 4;
+    const int gsize = GN * ntm;
+    const int grp_t = id / gsize, rem = id - grp_t * gsize;
+    const int gn = min(GN, ntn - grp_t * GN);
+    const int mt = rem / gn, nt = grp_t * GN + (rem - (rem / gn) * gn);
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // LDS-DMA: 64 pieces (1 KiB = 8 rows x 128 B) per K-tile, wave w moves A pieces 4w..4w+3 and W pieces 4w..4w+3
+    const bf16_t* asrc[4];
+    const bf16_t* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        asrc[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + c * 8;
+        wsrc[i] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw + c * 8;
+    }
+    auto dma_a = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE_BYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BK), (lptr_t)(base + i * 1024), 16, 0, 0);
+    };
+    auto dma_w = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE_BYTES + A_BYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kt * BK), (lptr_t)(base + i * 1024), 16, 0, 0);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fq = lane >> 4;
+    // fragment byte offsets inside a stage (row*128 + swizzled chunk), kk adds (4 ^ ...) -> precompute both kk
+    int aoff[8][2], boff[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int row = wm * 128 + mi * 16 + frow;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) aoff[mi][kk] = row * 128 + (((kk * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int row = wn * 64 + ni * 16 + frow;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) boff[ni][kk] = A_BYTES + row * 128 + (((kk * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+    }
+
+    bf16x8 af[4][2], b0[2][2], b1[2][2];
+    auto read_a = [&](const char* st, int mh) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) af[i][kk] = *(const bf16x8*)(st + aoff[mh * 4 + i][kk]);
+    };
+    auto read_b = [&](const char* st, int nh, bf16x8 (&b)[2][2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) b[i][kk] = *(const bf16x8*)(st + boff[nh * 2 + i][kk]);
+    };
+    auto mma = [&](int mh, int nh, bf16x8 (&b)[2][2]) {
+        if (SETPRIO) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[mh * 4 + i][nh * 2 + j] =
+                        __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kk], b[j][kk], acc[mh * 4 + i][nh * 2 + j], 0, 0, 0);
+        if (SETPRIO) __builtin_amdgcn_s_setprio(0);
+    };
+
+    const int nk = g.K / BK;
+    dma_a(0, 0);
+    dma_w(0, 0);
+    PP_VM0();
+    PP_BARRIER();
+    if (grp == 1) PP_BARRIER();  // group B starts one phase late
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const char* st = smem + (kt & 1) * STAGE_BYTES;
+        const bool more = kt + 1 < nk;
+        // R0
+        if (more) dma_a((kt + 1) & 1, kt + 1);
+        read_a(st, 0);
+        read_b(st, 0, b0);
+        PP_LGKM0();
+        PP_BARRIER();
+        mma(0, 0, b0);  // C0
+        PP_BARRIER();
+        // R1
+        if (more) dma_w((kt + 1) & 1, kt + 1);
+        read_b(st, 1, b1);
+        PP_LGKM0();
+        PP_BARRIER();
+        mma(0, 1, b1);  // C1
+        PP_BARRIER();
+        // R2
+        read_a(st, 1);
+        PP_LGKM0();
+        PP_BARRIER();
+        mma(1, 1, b1);  // C2
+        PP_BARRIER();
+        // R3 (nothing left to read: B half 0 is still resident); next K-tile must have landed one phase before
+        // group A starts reading it
+        PP_VM0();
+        PP_BARRIER();
+        mma(1, 0, b0);  // C3
+        PP_VM0();
+        PP_BARRIER();
+    }
+    if (grp == 0) PP_BARRIER();  // group A waits out group B's last phase
+
+    const int mrow0 = m0 + wm * 128 + fq * 4, ncol0 = n0 + wn * 64 + frow;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mrow0 + mi * 16 + r;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = ncol0 + ni * 16;
+                if (n < g.N) g.C[(size_t)m * g.ldc + n] = f2bf(acc[mi][ni][r]);
+            }
+        }
+}
+
+template <bool SETPRIO, int GRPMODE>
+int launch_pp(const GemmArgs& g, hipStream_t s) {
+    constexpr int LDS = 2 * 512 * 128;
+    static bool attr_set = false;
+    auto fn = gemm_pp_kernel<SETPRIO, GRPMODE>;
+    if (!attr_set) {
+        MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int ntm = (g.M + 255) / 256, ntn = (g.N + 255) / 256;
+    hipLaunchKernelGGL(fn, dim3(ntm * ntn), dim3(512), LDS, s, g);
+    MM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int RING, bool PREFETCH>
+int launch_big(const GemmArgs& g, hipStream_t s) {
+    constexpr int LDS = RING * 512 * 64;
+    static bool attr_set = false;
+    auto fn = gemm_big_kernel<RING, PREFETCH>;
+    if (!attr_set) {
+        MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int ntm = (g.M + 255) / 256, ntn = (g.N + 255) / 256;
+    hipLaunchKernelGGL(fn, dim3(ntm * ntn), dim3(256), LDS, s, g);
+    MM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int BM, int BN, int BK, int WM, int WN, int STAGES, int MINW>
 int launch_var(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = STAGES * (BM + BN) * BK * 2;
@@ -281,6 +587,13 @@ int launch_gemm_variant(int variant, const GemmArgs& g, hipStream_t s) {
         case 16: return launch_var32<256, 128, 4, 4, 3, 4>(g, s);
         case 17: return launch_var<256, 128, 64, 4, 4, 3, 4>(g, s);
         case 18: return launch_var<256, 256, 64, 4, 2, 2, 2>(g, s);
+        case 30: return launch_pp<false, 0>(g, s);
+        case 31: return launch_pp<true, 0>(g, s);
+        case 32: return launch_pp<false, 1>(g, s);
+        case 33: return launch_pp<false, 2>(g, s);
+        case 20: return launch_big<4, false>(g, s);
+        case 21: return launch_big<4, true>(g, s);
+        case 22: return launch_big<5, true>(g, s);
     }
     return mm_fail("gemm_variant: unknown variant %d", variant);
 }

@@ -70,7 +70,9 @@ class LLaDAForMultiModalGeneration:
         self._lib = abi.lib()
         self._handle = C.c_void_p()
         self._ws = None
-        self._ws_shape = (0, 0)
+        self._ws1 = None
+        self._handle1 = None
+        self._split = None
         self.n_kv_heads = config.get("n_kv_heads") or config.n_heads
         self.vocab = config.get("embedding_size") or config.vocab_size
         self.mlp_hidden = config.get("mlp_hidden_size") or config.get("mlp_ratio", 4) * config.d_model
@@ -151,53 +153,122 @@ class LLaDAForMultiModalGeneration:
         return cls(config, _Lazy(), **kw)
 
     # ---- workspace ------------------------------------------------------------------------------------------------
-    def _ensure_ws(self, B: int, L: int) -> None:
-        need = self._lib.mmada_workspace_bytes(self._handle, B, L)
-        if self._ws is None or self._ws.numel() < need:
-            grow = max(need, self._lib.mmada_workspace_bytes(self._handle, max(B, self.max_batch), L))
-            self._ws = torch.empty(grow + 256, dtype=torch.uint8, device=self.device)
-            base = (self._ws.data_ptr() + 255) // 256 * 256
-            abi.check(self._lib.mmada_set_workspace(self._handle, base, grow), "mmada_set_workspace")
+    def _ensure_ws(self, B: int, L: int, lane: int = 0) -> None:
+        h = self._lane_handle(lane)
+        need = self._lib.mmada_workspace_bytes(h, B, L)
+        ws = self._ws if lane == 0 else self._ws1
+        if ws is None or ws.numel() < need:
+            grow = max(need, self._lib.mmada_workspace_bytes(h, max(B, self.max_batch), L))
+            ws = torch.empty(grow + 256, dtype=torch.uint8, device=self.device)
+            base = (ws.data_ptr() + 255) // 256 * 256
+            abi.check(self._lib.mmada_set_workspace(h, base, grow), "mmada_set_workspace")
+            if lane == 0:
+                self._ws = ws
+            else:
+                self._ws1 = ws
+
+    def _lane_handle(self, lane: int):
+        if lane == 0:
+            return self._handle
+        if getattr(self, "_handle1", None) is None:
+            self._handle1 = C.c_void_p()
+            self._ws1 = None
+            abi.check(self._lib.mmada_clone_shared(self._handle, C.byref(self._handle1)), "mmada_clone_shared")
+        return self._handle1
 
     # ---- forward ---------------------------------------------------------------------------------------------------
     def forward_body(self, input_ids: torch.Tensor) -> None:
-        """Embedding + all blocks; the final residual stream stays resident for head_rows()."""
+        """Embedding + all blocks; the final residual stream stays resident for head_rows().
+
+        Tensor parallel (tp_size > 1): after each of the two row-parallel GEMMs of a block the partial residual
+        stream is all-reduced over RCCL.  With B >= 2 the batch is split into two micro-batches living in two
+        activation contexts over the same weights, and the all-reduce of one micro-batch is issued asynchronously
+        so that it overlaps the other micro-batch's GEMMs / attention."""
         ids = input_ids.to(device=self.device, dtype=torch.long).contiguous()
         B, L = ids.shape
-        self._ensure_ws(B, L)
         st = abi.stream_ptr()
-        if self.tp_size == 1:
-            abi.check(self._lib.mmada_forward_body(self._handle, ids.data_ptr(), B, L, st), "mmada_forward_body")
+        microbatch = B >= 2 and (self.tp_size > 1 or os.environ.get("MMADA_MICROBATCH") == "1")
+        self._split = None
+        if not microbatch:
+            self._ensure_ws(B, L)
+            if self.tp_size == 1:
+                abi.check(self._lib.mmada_forward_body(self._handle, ids.data_ptr(), B, L, st), "mmada_forward_body")
+            else:
+                import torch.distributed as dist
+
+                abi.check(self._lib.mmada_embed(self._handle, ids.data_ptr(), B, L, st), "mmada_embed")
+                for i in range(self.config.n_layers):
+                    for seg in (self._lib.mmada_attn_partial, self._lib.mmada_mlp_partial):
+                        abi.check(seg(self._handle, i, st), "mmada_*_partial")
+                        dist.all_reduce(self._stream_view())
         else:
             import torch.distributed as dist
 
-            abi.check(self._lib.mmada_embed(self._handle, ids.data_ptr(), B, L, st), "mmada_embed")
+            reduce = dist.is_available() and dist.is_initialized()
+            B0 = (B + 1) // 2
+            parts = [ids[:B0].contiguous(), ids[B0:].contiguous()]
+            handles = [self._lane_handle(0), self._lane_handle(1)]
+            for j in (0, 1):
+                self._ensure_ws(parts[j].shape[0], L, lane=j)
+                abi.check(self._lib.mmada_embed(handles[j], parts[j].data_ptr(), parts[j].shape[0], L, st), "mmada_embed")
+            pending = [None, None]
             for i in range(self.config.n_layers):
                 for seg in (self._lib.mmada_attn_partial, self._lib.mmada_mlp_partial):
-                    abi.check(seg(self._handle, i, st), "mmada_*_partial")
-                    dist.all_reduce(self._stream_view())
+                    for j in (0, 1):
+                        if pending[j] is not None:
+                            pending[j].wait()  # this lane's previous all-reduce (ran under the other lane's kernels)
+                            pending[j] = None
+                        abi.check(seg(handles[j], i, st), "mmada_*_partial")
+                        if reduce:
+                            pending[j] = dist.all_reduce(self._stream_view(j), async_op=True)
+            for j in (0, 1):
+                if pending[j] is not None:
+                    pending[j].wait()
+            self._split = B0
         self._shape = (B, L)
 
-    def _stream_view(self) -> torch.Tensor:
+    def _stream_view(self, lane: int = 0) -> torch.Tensor:
         """Torch view of the library's current residual-stream buffer (inside our workspace tensor)."""
-        p = self._lib.mmada_stream_ptr(self._handle)
-        n = self._lib.mmada_stream_bytes(self._handle)
-        off = p - self._ws.data_ptr()
-        return self._ws[off:off + n].view(torch.bfloat16)
+        h = self._lane_handle(lane)
+        ws = self._ws if lane == 0 else self._ws1
+        p = self._lib.mmada_stream_ptr(h)
+        n = self._lib.mmada_stream_bytes(h)
+        off = p - ws.data_ptr()
+        return ws[off:off + n].view(torch.bfloat16)
 
     def head_rows(self, rows: torch.Tensor, col_begin: int, col_end: int) -> torch.Tensor:
-        """logits[r] = lm_head[col_begin:col_end] · ln_f(x[rows[r]]), rows = b*L + l (int32, device)."""
+        """logits[r] = lm_head[col_begin:col_end] · ln_f(x[rows[r]]), rows = b*L + l (int32, device).
+
+        `rows` must be batch-major with the same number of rows per batch element (what generate_ti2ti builds)."""
         rows = rows.to(device=self.device, dtype=torch.int32).contiguous()
         out = torch.empty((rows.numel(), col_end - col_begin), dtype=torch.bfloat16, device=self.device)
-        abi.check(self._lib.mmada_head_rows(self._handle, rows.data_ptr(), rows.numel(), col_begin, col_end,
-                                            out.data_ptr(), abi.stream_ptr()), "mmada_head_rows")
+        st = abi.stream_ptr()
+        if getattr(self, "_split", None) is None:
+            abi.check(self._lib.mmada_head_rows(self._handle, rows.data_ptr(), rows.numel(), col_begin, col_end,
+                                                out.data_ptr(), st), "mmada_head_rows")
+            return out
+        B, L = self._shape
+        if rows.numel() % B:
+            raise ValueError("head_rows on a micro-batched forward needs an equal row count per batch element")
+        per_b, B0 = rows.numel() // B, self._split
+        cut = B0 * per_b
+        r1 = (rows[cut:] - B0 * L).contiguous()  # second micro-batch indexes its own batch from 0
+        abi.check(self._lib.mmada_head_rows(self._handle, rows.data_ptr(), cut, col_begin, col_end, out.data_ptr(), st),
+                  "mmada_head_rows")
+        abi.check(self._lib.mmada_head_rows(self._handle1, r1.data_ptr(), rows.numel() - cut, col_begin, col_end,
+                                            out[cut:].data_ptr(), st), "mmada_head_rows")
         return out
 
     def hidden_state(self) -> torch.Tensor:
         """Residual stream after the last block, [B, L, d] (parity tap)."""
         B, L = self._shape
         out = torch.empty((B, L, self.config.d_model), dtype=torch.bfloat16, device=self.device)
-        abi.check(self._lib.mmada_read_stream(self._handle, out.data_ptr(), abi.stream_ptr()), "mmada_read_stream")
+        st = abi.stream_ptr()
+        if getattr(self, "_split", None) is None:
+            abi.check(self._lib.mmada_read_stream(self._handle, out.data_ptr(), st), "mmada_read_stream")
+        else:
+            abi.check(self._lib.mmada_read_stream(self._handle, out.data_ptr(), st), "mmada_read_stream")
+            abi.check(self._lib.mmada_read_stream(self._handle1, out[self._split:].data_ptr(), st), "mmada_read_stream")
         return out
 
     def debug_buffer(self, which: int) -> torch.Tensor:
@@ -240,6 +311,9 @@ class LLaDAForMultiModalGeneration:
 
     def __del__(self):
         try:
+            if getattr(self, "_handle1", None) is not None and self._handle1.value:
+                self._lib.mmada_destroy(self._handle1)
+                self._handle1 = None
             if getattr(self, "_handle", None) and self._handle.value:
                 self._lib.mmada_destroy(self._handle)
                 self._handle = C.c_void_p()

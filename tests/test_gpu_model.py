@@ -336,3 +336,45 @@ def test_tensor_parallel_slices_on_one_gpu(tiny_model, tp):
     lg = ranks[0].head_rows(rows, synth.TEXT_VOCAB, synth.TEXT_VOCAB + 512).float().cpu()
     lr = tiny_model.head_rows(rows, synth.TEXT_VOCAB, synth.TEXT_VOCAB + 512).float().cpu()
     assert (lg - lr).abs().max().item() < 2.0 ** -5 * lr.abs().max().item()
+
+
+def test_microbatched_overlap_path_matches_single_context(tiny_model, monkeypatch):
+    """The tensor-parallel overlap schedule (two activation contexts over shared weights, async all-reduce of one
+    micro-batch under the other's kernels) exercised on one GPU with a single-rank RCCL group: results must be
+    bit-identical to the plain path, for forward_body / head_rows and for a whole generate_ti2ti run."""
+    import torch.distributed as dist
+
+    from mmada_parallel_amd import generate_ti2ti
+
+    job = tiny_job()
+    ids = job["input_ids"].repeat(3, 1).to(DEV)
+    ids[1, :4] = torch.tensor([5, 6, 7, 8], device=DEV)
+    ids[2, :4] = torch.tensor([9, 10, 11, 12], device=DEV)
+    rows = (torch.arange(3, device=DEV)[:, None] * ids.shape[1] + torch.arange(10, 40, device=DEV)[None, :]).reshape(-1).int()
+    tiny_model.forward_body(ids)
+    ref_h = tiny_model.hidden_state().clone()
+    ref_l = tiny_model.head_rows(rows, 100, 612).clone()
+    kw = dict(text_steps=8, timesteps=4, temperature=0.0, text_temperature=0.0, cfg_scale=2.5, cfg_img=4.0,
+              uncon_text=job["uncon_text"], uncon_image=job["uncon_image"], return_state=True)
+    args = (job["text_start"], job["text_end"], job["image_start"], job["seq_len"], job["newline_every"])
+    ref_final = generate_ti2ti(tiny_model, ids, *args, **kw)[2]
+
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        monkeypatch.setenv("MMADA_MICROBATCH", "1")
+        tiny_model.forward_body(ids)
+        assert tiny_model._split == 2
+        assert torch.equal(tiny_model.hidden_state(), ref_h)
+        assert torch.equal(tiny_model.head_rows(rows, 100, 612), ref_l)
+        got_final = generate_ti2ti(tiny_model, ids, *args, **kw)[2]
+        assert torch.equal(got_final, ref_final)
+    finally:
+        monkeypatch.delenv("MMADA_MICROBATCH", raising=False)
+        tiny_model.forward_body(ids[:1])  # back to the single-context state for the other tests
+        if created:
+            dist.destroy_process_group()
