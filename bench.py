@@ -71,6 +71,21 @@ def cpu_baseline(cfg, job, sample_layers=2, reps=2):
                       f"{per_forward:.2f} s/forward"}
 
 
+def measured_traffic(kernel):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json:
+    FETCH_SIZE / WRITE_SIZE collected separately, gfx950 correction applied), averaged over the launch mix of one
+    image.  PMC collection cannot run inside the timed bench; null if the kernel was not profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        if t["kernel"] != kernel:
+            return None
+        mix = t["launch_mix"]
+        return sum(t["per_launch_bytes"][k] * mix[k] for k in mix) / sum(mix.values())
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,7 +185,7 @@ def main():
                        "job_mfma_frac": value * fl_img / 1e12 / (world * MFMA_BF16_PEAK_TFLOPS),
                        "kernels": kinds},
             "roofline": {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None},
+                         "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_traffic(KIND_NAMES[dom])},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, job)
