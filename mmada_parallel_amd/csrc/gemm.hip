@@ -49,95 +49,100 @@ MM_DEVICE float silu_bf16(float g) {
     return bfround(g / (1.0f + expf(-g)));
 }
 
-template <int EPI, int BM, int WM, int WN>
-__global__ __launch_bounds__(NTHREADS, 4) void gemm_bt_kernel(GemmArgs g) {
-    static_assert(WM * WN == NWAVES, "16 waves");
-    constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
-    static_assert(TM % 16 == 0 && TN % 32 == 0, "wave tile");
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
-    constexpr int PA_TOTAL = BM / 8;               // 1-KiB LDS-DMA pieces (8 rows x 128 B) of the A tile
-    constexpr int PA = (PA_TOTAL + NWAVES - 1) / NWAVES, PB = BN / 8 / NWAVES;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-
-    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-    // XCD-aware + grouped tile order: GN column tiles x all row tiles form one group
-    const int id = xcd_remap(blockIdx.x, gridDim.x);
+// Tile sequence number -> (row tile, column tile): grouped order, GN column tiles x all row tiles per group, so
+// workgroups with neighbouring sequence numbers (same XCD after xcd_remap) share A and W panels in their L2.
+MM_DEVICE void tile_coords(int t, int ntm, int ntn, int& mt, int& nt) {
     constexpr int GN = 4;
     const int gsize = GN * ntm;
-    const int grp = id / gsize, rem = id - grp * gsize;
+    const int grp = t / gsize, rem = t - grp * gsize;
     const int gn = min(GN, ntn - grp * GN);
-    const int mt = rem / gn, nt = grp * GN + (rem - (rem / gn) * gn);
-    const int m0 = mt * BM, n0 = nt * BN;
+    mt = rem / gn;
+    nt = grp * GN + (rem - mt * gn);
+}
 
-    // ---- staging addresses: wave w issues A pieces w, w+16, ... and W pieces w*PB .. w*PB+PB-1 ----
-    const bf16_t* asrc[PA];
-    const bf16_t* wsrc[PB];
+template <int BM, int WM, int WN>
+struct Tile {
+    static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    static_assert(WM * WN == NWAVES && TM % 16 == 0 && TN % 32 == 0, "wave tile");
+    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
+    static constexpr int PA_TOTAL = BM / 8;  // 1-KiB LDS-DMA pieces (8 rows x 128 B) of the A tile
+    static constexpr int PA = (PA_TOTAL + NWAVES - 1) / NWAVES, PB = BN / 8 / NWAVES;
+};
+
+// acc += A[m0.., k-tiles k0..k1) · W[n0.., same k-tiles)^T.  Two LDS stages, one raw s_barrier per K-tile:
+//   wait(tile t landed, my reads of tile t-1 done) ; barrier ; issue tile t+1 ; multiply tile t.
+template <int BM, int WM, int WN>
+MM_DEVICE void mainloop(const GemmArgs& g, char* smem, int m0, int n0, int k0, int k1,
+                        f32x4 (&acc)[Tile<BM, WM, WN>::FM][Tile<BM, WM, WN>::FN], int wave, int lane) {
+    using T = Tile<BM, WM, WN>;
+    const int wm = wave / WN, wn = wave % WN;
+    // staging addresses: wave w issues A pieces w, w+16, ... and W pieces w*PB .. w*PB+PB-1
+    const bf16_t* asrc[T::PA];
+    const bf16_t* wsrc[T::PB];
 #pragma unroll
-    for (int i = 0; i < PA; ++i) {
-        const int piece = min(wave + i * NWAVES, PA_TOTAL - 1);
+    for (int i = 0; i < T::PA; ++i) {
+        const int piece = min(wave + i * NWAVES, T::PA_TOTAL - 1);
         const int row = piece * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);  // logical 16-B chunk this lane fetches
         asrc[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + c * 8;
     }
 #pragma unroll
-    for (int i = 0; i < PB; ++i) {
-        const int row = (wave * PB + i) * 8 + (lane >> 3);
+    for (int i = 0; i < T::PB; ++i) {
+        const int row = (wave * T::PB + i) * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);
         wsrc[i] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw + c * 8;
     }
-
-    f32x4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
     auto stage = [&](int buf, int kt) {
-        char* base = smem + buf * STAGE_BYTES;
+        char* base = smem + buf * T::STAGE_BYTES;
 #pragma unroll
-        for (int i = 0; i < PA; ++i)
-            if (PA_TOTAL % NWAVES == 0 || wave + i * NWAVES < PA_TOTAL)  // wave-uniform
+        for (int i = 0; i < T::PA; ++i)
+            if (T::PA_TOTAL % NWAVES == 0 || wave + i * NWAVES < T::PA_TOTAL)  // wave-uniform
                 glds16(asrc[i] + kt * BK, base + (wave + i * NWAVES) * 1024);
 #pragma unroll
-        for (int i = 0; i < PB; ++i) glds16(wsrc[i] + kt * BK, base + A_BYTES + (wave * PB + i) * 1024);
+        for (int i = 0; i < T::PB; ++i) glds16(wsrc[i] + kt * BK, base + T::A_BYTES + (wave * T::PB + i) * 1024);
     };
-
     const int frow = lane & 15;  // row inside a 16-row fragment
     const int fq = lane >> 4;    // which 8-element k group of the 32-wide MFMA step
 
-    const int nk = g.K / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
+    // every wave's LDS reads of the previous tile of this workgroup are done before stage 0 is overwritten
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    stage(0, k0);
+    for (int kt = k0; kt < k1; ++kt) {
+        const int cur = (kt - k0) & 1;
         // this wave's pieces of tile kt have landed and its LDS reads of tile kt-1 are done; then everyone's
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        const char* At = smem + (kt & 1) * STAGE_BYTES;
-        const char* Wt = At + A_BYTES;
+        if (kt + 1 < k1) stage(cur ^ 1, kt + 1);
+        const char* At = smem + cur * T::STAGE_BYTES;
+        const char* Wt = At + T::A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 a[FM], b[FN];
+            bf16x8 a[T::FM], b[T::FN];
 #pragma unroll
-            for (int mi = 0; mi < FM; ++mi) {
-                const int row = wm * TM + mi * 16 + frow;
+            for (int mi = 0; mi < T::FM; ++mi) {
+                const int row = wm * T::TM + mi * 16 + frow;
                 a[mi] = *(const bf16x8*)(At + row * 128 + (((kk * 4 + fq) ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int ni = 0; ni < FN; ++ni) {
-                const int row = wn * TN + ni * 16 + frow;
+            for (int ni = 0; ni < T::FN; ++ni) {
+                const int row = wn * T::TN + ni * 16 + frow;
                 b[ni] = *(const bf16x8*)(Wt + row * 128 + (((kk * 4 + fq) ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int mi = 0; mi < FM; ++mi)
+            for (int mi = 0; mi < T::FM; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < FN; ++ni)
+                for (int ni = 0; ni < T::FN; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
         }
     }
+}
 
+template <int EPI, int BM, int WM, int WN>
+MM_DEVICE void epilogue(const GemmArgs& g, int m0, int n0,
+                        f32x4 (&acc)[Tile<BM, WM, WN>::FM][Tile<BM, WM, WN>::FN], int wave, int lane) {
+    using T = Tile<BM, WM, WN>;
+    constexpr int TM = T::TM, TN = T::TN, FM = T::FM, FN = T::FN;
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fq = lane >> 4;
     // ---- epilogue: acc[mi][ni][r] = D[m][n], m = m0+wm*TM+mi*16+fq*4+r, n = n0+wn*TN+ni*16+frow ----
     const int mrow0 = m0 + wm * TM + fq * 4;
     const int wcol0 = n0 + wn * TN;  // first column of this wave (wave-uniform)
@@ -228,6 +233,102 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bt_kernel(GemmArgs g) {
     }
 }
 
+// Data-parallel launch: one workgroup per output tile.
+template <int EPI, int BM, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS, 4) void gemm_bt_kernel(GemmArgs g) {
+    using T = Tile<BM, WM, WN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+    int mt, nt;
+    tile_coords(xcd_remap(blockIdx.x, gridDim.x), ntm, ntn, mt, nt);
+    f32x4 acc[T::FM][T::FN];
+#pragma unroll
+    for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mainloop<BM, WM, WN>(g, smem, mt * BM, nt * BN, 0, g.K / BK, acc, wave, lane);
+    epilogue<EPI, BM, WM, WN>(g, mt * BM, nt * BN, acc, wave, lane);
+}
+
+// Stream-K launch: a persistent grid of one workgroup per CU; the (tile, K-tile) iteration space is cut into equal
+// contiguous shares, so no CU idles in a partial last wave (M x N = 2438 x 4096 is only 160 tiles of 256 x 256).
+// A tile whose K range is split is finished by the workgroup that holds its k = 0 end: the others publish their
+// fp32 partial accumulators (always the FIRST thing they do, so the owner — which reaches that tile LAST — rarely
+// waits) with an agent-scope release, and the owner adds them in workgroup order (deterministic) after an
+// agent-scope acquire (guide G16).  Flags carry a per-launch epoch: nothing is ever reset.
+struct StreamKArgs {
+    float* partial;        // [grid][16 fragments][1024 threads] x f32x4
+    unsigned* flags;       // [grid]
+    unsigned epoch;
+    int ntm, ntn, nk, units;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(NTHREADS, 4) void gemm_streamk_kernel(GemmArgs g, StreamKArgs sk) {
+    constexpr int BM = 256, WM = 4, WN = 4;
+    using T = Tile<BM, WM, WN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = gridDim.x;
+    const int me = xcd_remap(blockIdx.x, G);  // consecutive shares stay on one XCD
+    auto share_begin = [&](int b) { return (int)(((long long)b * sk.units) / G); };
+    int u = share_begin(me);
+    const int uend = share_begin(me + 1);
+    while (u < uend) {
+        const int t = u / sk.nk, k0 = u - t * sk.nk;
+        const int k1 = min(sk.nk, k0 + (uend - u));
+        int mt, nt;
+        tile_coords(t, sk.ntm, sk.ntn, mt, nt);
+        f32x4 acc[T::FM][T::FN];
+#pragma unroll
+        for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+            for (int j = 0; j < T::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        mainloop<BM, WM, WN>(g, smem, mt * BM, nt * BN, k0, k1, acc, wave, lane);
+        if (k0 != 0) {
+            // not the owner: publish the partial (one per workgroup at most: always its first segment)
+            f32x4* slot = (f32x4*)sk.partial + (size_t)me * (T::FM * T::FN * NTHREADS) + tid;
+#pragma unroll
+            for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+                for (int j = 0; j < T::FN; ++j) slot[(i * T::FN + j) * NTHREADS] = acc[i][j];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_store(sk.flags + me, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else {
+            if (k1 != sk.nk) {
+                // owner of a split tile: add the partials of the following workgroups, in order
+                const int tile_end = (t + 1) * sk.nk;
+                for (int j = me + 1; j < G && share_begin(j) < tile_end; ++j) {
+                    if (tid == 0) {
+                        unsigned spins = 0;
+                        while (__hip_atomic_load(sk.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
+                            __builtin_amdgcn_s_sleep(8);
+                            if (++spins > (1u << 24)) break;  // never hang the device: a lost partial shows as a wrong tile
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    }
+                    __syncthreads();
+                    const f32x4* slot = (const f32x4*)sk.partial + (size_t)j * (T::FM * T::FN * NTHREADS) + tid;
+#pragma unroll
+                    for (int i = 0; i < T::FM; ++i)
+#pragma unroll
+                        for (int jj = 0; jj < T::FN; ++jj) acc[i][jj] += slot[(i * T::FN + jj) * NTHREADS];
+                }
+            }
+            epilogue<EPI, BM, WM, WN>(g, mt * BM, nt * BN, acc, wave, lane);
+        }
+        u += k1 - k0;
+    }
+}
+
 template <int EPI, int BM, int WM, int WN>
 int launch_cfg(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = 2 * (BM + BN) * 128;
@@ -251,6 +352,7 @@ int pick_bm(int M, int N) {
         return e ? atoi(e) : 0;
     }();
     if (forced == 128 || forced == 160 || forced == 192 || forced == 224 || forced == 256) return forced;
+    if (M == 0 && N == 0) return 0;  // query: "is a row-tile height forced?" (no)
     const int cand[5] = {256, 192, 128, 160, 224};
     const float handicap[5] = {1.0f, 1.0f, 1.04f, 1.08f, 1.08f};
     const int ntn = (N + BN - 1) / BN;
@@ -265,8 +367,81 @@ int pick_bm(int M, int N) {
     return best;
 }
 
+// Library-owned stream-K scratch (one per device): partial accumulators + epoch flags.  All GEMMs of a device
+// are issued on one stream at a time (the forward is a single in-order launch sequence).
+struct StreamKScratch {
+    float* partial = nullptr;
+    unsigned* flags = nullptr;
+    unsigned epoch = 0;
+    int grid = 0;
+};
+
+int streamk_scratch(StreamKScratch** out) {
+    static StreamKScratch per_dev[16];
+    int dev = 0;
+    MM_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return mm_fail("gemm: device index %d out of range", dev);
+    StreamKScratch& w = per_dev[dev];
+    if (!w.partial) {
+        hipDeviceProp_t prop;
+        MM_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
+        w.grid = prop.multiProcessorCount;  // one 1024-thread, 128-KiB-LDS workgroup per CU: all co-resident
+        MM_CHECK_HIP(hipMalloc(&w.partial, (size_t)w.grid * 16 * NTHREADS * sizeof(f32x4)));
+        MM_CHECK_HIP(hipMalloc(&w.flags, (size_t)w.grid * sizeof(unsigned)));
+        MM_CHECK_HIP(hipMemset(w.flags, 0, (size_t)w.grid * sizeof(unsigned)));
+    }
+    *out = &w;
+    return 0;
+}
+
+// Measured on MI355X (8B block shapes, M = 2438): stream-K is 15-27 % SLOWER than the data-parallel grid with the
+// row-tile picker (qkv 784 vs 1079 TFLOP/s, attn_out 615 vs 849, gate/up 923 vs 1137, down 842 vs 967).  With one
+// tile per workgroup all 256 CUs walk K in lockstep, so the A/W panels shared by neighbouring tiles are fetched
+// once per XCD L2; stream-K starts every workgroup at a different K offset and loses that sharing.  Kept as an
+// opt-in (MMADA_GEMM_STREAMK=1) for shapes with very few tiles.
+bool streamk_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("MMADA_GEMM_STREAMK");
+        return e && e[0] == '1';
+    }();
+    return on;
+}
+
+template <int EPI>
+int launch_streamk(const GemmArgs& g, hipStream_t s) {
+    StreamKScratch* w;
+    if (streamk_scratch(&w)) return 1;
+    constexpr int LDS = 2 * (256 + BN) * 128;
+    static bool attr_set = false;
+    auto fn = gemm_streamk_kernel<EPI>;
+    if (!attr_set) {
+        MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    StreamKArgs sk;
+    sk.partial = w->partial;
+    sk.flags = w->flags;
+    sk.epoch = ++w->epoch;
+    if (sk.epoch == 0) sk.epoch = ++w->epoch;  // 0 is the "never written" value
+    sk.ntm = (g.M + 255) / 256;
+    sk.ntn = (g.N + BN - 1) / BN;
+    sk.nk = g.K / BK;
+    sk.units = sk.ntm * sk.ntn * sk.nk;
+    hipLaunchKernelGGL(fn, dim3(w->grid), dim3(NTHREADS), LDS, s, g, sk);
+    MM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int EPI>
 int launch_t(const GemmArgs& g, hipStream_t s) {
+    // stream-K when the 256x256 tile grid does not fill whole waves of CUs and there is enough K work to share
+    const int ntiles = ((g.M + 255) / 256) * ((g.N + BN - 1) / BN), nk = g.K / BK;
+    if (streamk_enabled() && pick_bm(0, 0) == 0) {
+        StreamKScratch* w;
+        if (streamk_scratch(&w)) return 1;
+        if (ntiles % w->grid != 0 && ntiles < 8 * w->grid && (long long)ntiles * nk >= 4LL * w->grid)
+            return launch_streamk<EPI>(g, s);
+    }
     switch (pick_bm(g.M, g.N)) {
         case 256: return launch_cfg<EPI, 256, 4, 4>(g, s);
         case 192: return launch_cfg<EPI, 192, 4, 4>(g, s);
