@@ -159,6 +159,24 @@ int mmada_image_commit(mmada_handle* h, int64_t* ids, int B, int L, const int32_
                        const int32_t* sampled_in, const void* p_in, const void* noise, float remask_temp,
                        const int32_t* mask_len_sched, int text_vocab_size, int codebook_size, void* stream);
 
+/* ---- (M variant) sampler math of MMadaModelLM.interleave_generate, MMaDA-Parallel-M/models/modeling_mmada.py:117-248 --
+ * Text step (:179-207): logits = cond + text_cfg * (uncond - cond) with bf16 rounding per op, then exactly
+ * mmada_text_select on the combined logits.  x0_in (optional, device int32 [B,T]) supplies an externally sampled x0
+ * (the reference's float64 Gumbel-max when text_temperature > 0, :49-60); NULL = first-index argmax. */
+int mmada_text_select_cfg(mmada_handle* h, const void* cond, const void* uncond, float text_cfg, const int32_t* x0_in,
+                          int B, int T, int V, int ld_logits, int64_t* ids, int L, int text_start, const int32_t* k,
+                          void* scratch, void* stream);
+/* Image logits (:216): (1 + image_cfg) * cond - image_cfg * uncond (bf16 per op) -> softmax -> bf16 probabilities
+ * (probs_out, consumed by torch.multinomial :220-222), first-index argmax and its probability. */
+int mmada_image_probs_m(mmada_handle* h, const void* cond, const void* uncond, int B, int N, int CB, float image_cfg,
+                        void* probs_out, int32_t* argmax_out, void* pmax_out, void* stream);
+/* Re-mask + write-back (:224-241, MMaDA-Parallel-M/models/sampling.py:31-36): confidence = log(clamp(p,1e-20)) +
+ * temp * gumbel (bf16 ops; gumbel: bf16 device [B,N], required); masked <=> confidence < sorted[mask_len]
+ * (ties with the cut-off are NOT masked); known ids are kept unclamped. */
+int mmada_image_commit_m(mmada_handle* h, int64_t* ids, int B, int L, const int32_t* pos_map, int N,
+                         const int32_t* sampled_in, const void* p_in, const void* gumbel, float remask_temp,
+                         const int32_t* mask_len_sched, int text_vocab_size, void* stream);
+
 /* (M variant) LFQ codebook gather, MMaDA-Parallel-M/models/modeling_magvitv2.py:186-194,208-221:
  * out[b, c, n] = 2·bit_c(idx[b,n]) − 1 as bf16/f32, c in [0,nbits) with bit 0 = most significant
  * (mask = 2^(nbits-1-c)).  idx: device int64 [B,N]; out: device [B,nbits,N] (dtype_f32 ? float : bf16). */

@@ -5,5 +5,6 @@ Public surface mirrors the reference (tyfeld/MMaDA-Parallel, MMaDA-Parallel-A):
 """
 from .model import LLaDAForMultiModalGeneration, LLaDAConfigLite  # noqa: F401
 from .generators.parallel_generator import generate_ti2ti, cosine_schedule  # noqa: F401
+from .generators.interleave_generator import interleave_generate  # noqa: F401
 
-__all__ = ["LLaDAForMultiModalGeneration", "LLaDAConfigLite", "generate_ti2ti", "cosine_schedule"]
+__all__ = ["LLaDAForMultiModalGeneration", "LLaDAConfigLite", "generate_ti2ti", "interleave_generate", "cosine_schedule"]

@@ -53,6 +53,12 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "mmada_image_commit": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                    c_float, c_void_p, c_int, c_int, c_void_p]),
+    "mmada_text_select_cfg": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_int, c_int, c_int, c_int, c_void_p,
+                                      c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "mmada_image_probs_m": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                    c_void_p, c_void_p]),
+    "mmada_image_commit_m": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_float, c_void_p, c_int, c_void_p]),
     "mmada_lfq_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mmada_profile_begin": (c_int, [c_void_p, c_int]),
     "mmada_profile_end": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

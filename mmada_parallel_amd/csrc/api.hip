@@ -415,8 +415,34 @@ int mmada_text_select(mmada_handle* h, const void* logits, const void* noisy, in
                       int64_t* ids, int L, int text_start, const int32_t* k, void* scratch, void* stream) {
     if (!h || !logits || !ids || !k || !scratch) return mm_fail("mmada_text_select: null argument");
     if (text_start < 0 || text_start + T > L) return mm_fail("mmada_text_select: text span outside the sequence");
-    return launch_text_select((const bf16_t*)logits, (const bf16_t*)noisy, B, T, V, ld_logits, ids, L, text_start, k,
-                              scratch, h->cfg.mask_token_id, (hipStream_t)stream);
+    return launch_text_select((const bf16_t*)logits, (const bf16_t*)noisy, nullptr, 0.f, nullptr, B, T, V, ld_logits, ids, L,
+                              text_start, k, scratch, h->cfg.mask_token_id, (hipStream_t)stream);
+}
+
+int mmada_text_select_cfg(mmada_handle* h, const void* cond, const void* uncond, float text_cfg, const int32_t* x0_in,
+                          int B, int T, int V, int ld_logits, int64_t* ids, int L, int text_start, const int32_t* k,
+                          void* scratch, void* stream) {
+    if (!h || !cond || !uncond || !ids || !k || !scratch) return mm_fail("mmada_text_select_cfg: null argument");
+    if (text_start < 0 || text_start + T > L) return mm_fail("mmada_text_select_cfg: text span outside the sequence");
+    return launch_text_select((const bf16_t*)cond, nullptr, (const bf16_t*)uncond, text_cfg, x0_in, B, T, V, ld_logits, ids,
+                              L, text_start, k, scratch, h->cfg.mask_token_id, (hipStream_t)stream);
+}
+
+int mmada_image_probs_m(mmada_handle* h, const void* cond, const void* uncond, int B, int N, int CB, float image_cfg,
+                        void* probs_out, int32_t* argmax_out, void* pmax_out, void* stream) {
+    if (!h || !cond || !uncond || !argmax_out || !pmax_out) return mm_fail("mmada_image_probs_m: null argument");
+    const float one_plus = (float)(1.0 + (double)image_cfg);
+    return launch_image_probs((const bf16_t*)cond, (const bf16_t*)uncond, nullptr, B, N, CB, image_cfg, one_plus,
+                              (bf16_t*)probs_out, argmax_out, (bf16_t*)pmax_out, 1, (hipStream_t)stream);
+}
+
+int mmada_image_commit_m(mmada_handle* h, int64_t* ids, int B, int L, const int32_t* pos_map, int N,
+                         const int32_t* sampled_in, const void* p_in, const void* gumbel, float remask_temp,
+                         const int32_t* mask_len_sched, int text_vocab_size, void* stream) {
+    if (!h || !ids || !pos_map || !sampled_in || !p_in || !gumbel || !mask_len_sched)
+        return mm_fail("mmada_image_commit_m: null argument");
+    return launch_image_commit(ids, B, L, pos_map, N, sampled_in, (const bf16_t*)p_in, (const bf16_t*)gumbel, remask_temp,
+                               mask_len_sched, h->cfg.mask_token_id, text_vocab_size, 0, 1, (hipStream_t)stream);
 }
 
 int mmada_image_probs(mmada_handle* h, const void* cond, const void* unc_text, const void* unc_img, int B, int N, int CB,
@@ -424,7 +450,7 @@ int mmada_image_probs(mmada_handle* h, const void* cond, const void* unc_text, c
                       void* stream) {
     if (!h || !cond || !argmax_out || !pmax_out) return mm_fail("mmada_image_probs: null argument");
     return launch_image_probs((const bf16_t*)cond, (const bf16_t*)unc_text, (const bf16_t*)unc_img, B, N, CB, cfg_scale,
-                              cfg_img, (bf16_t*)probs_out, argmax_out, (bf16_t*)pmax_out, (hipStream_t)stream);
+                              cfg_img, (bf16_t*)probs_out, argmax_out, (bf16_t*)pmax_out, 0, (hipStream_t)stream);
 }
 
 int mmada_image_commit(mmada_handle* h, int64_t* ids, int B, int L, const int32_t* pos_map, int N,
@@ -432,7 +458,7 @@ int mmada_image_commit(mmada_handle* h, int64_t* ids, int B, int L, const int32_
                        const int32_t* mask_len_sched, int text_vocab_size, int codebook_size, void* stream) {
     if (!h || !ids || !pos_map || !sampled_in || !p_in || !mask_len_sched) return mm_fail("mmada_image_commit: null argument");
     return launch_image_commit(ids, B, L, pos_map, N, sampled_in, (const bf16_t*)p_in, (const bf16_t*)noise, remask_temp,
-                               mask_len_sched, h->cfg.mask_token_id, text_vocab_size, codebook_size, (hipStream_t)stream);
+                               mask_len_sched, h->cfg.mask_token_id, text_vocab_size, codebook_size, 0, (hipStream_t)stream);
 }
 
 int mmada_lfq_gather(mmada_handle* h, const int64_t* idx, int B, int N, int nbits, int dtype_f32, void* out,

@@ -53,10 +53,11 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
                      int Lq_rows, int Lkv, int out_row_stride_per_batch, int ld_out, hipStream_t s);
 
 // sampler.hip
-int launch_text_select(const bf16_t* logits, const bf16_t* noisy, int B, int T, int V, int ld, int64_t* ids, int L,
-                       int text_start, const int32_t* k, void* scratch, int mask_id, hipStream_t s);
+int launch_text_select(const bf16_t* logits, const bf16_t* noisy, const bf16_t* unc, float text_cfg, const int32_t* x0_in,
+                       int B, int T, int V, int ld, int64_t* ids, int L, int text_start, const int32_t* k, void* scratch,
+                       int mask_id, hipStream_t s);
 int launch_image_probs(const bf16_t* cond, const bf16_t* ut, const bf16_t* ui, int B, int N, int CB, float cfg_scale,
-                       float cfg_img, bf16_t* probs_out, int32_t* argmax_out, bf16_t* pmax_out, hipStream_t s);
+                       float cfg_img, bf16_t* probs_out, int32_t* argmax_out, bf16_t* pmax_out, int mvar, hipStream_t s);
 int launch_image_commit(int64_t* ids, int B, int L, const int32_t* pos_map, int N, const int32_t* sampled_in,
                         const bf16_t* p_in, const bf16_t* noise, float remask_temp, const int32_t* mask_len_sched,
-                        int mask_id, int text_vocab, int codebook, hipStream_t s);
+                        int mask_id, int text_vocab, int codebook, int mvar, hipStream_t s);

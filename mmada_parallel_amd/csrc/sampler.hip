@@ -17,8 +17,16 @@ constexpr int TB = 256;
 // Text step part 1: per (b,t) row — x0 = argmax(noisy or logits), conf = softmax_f64(logits)[x0]
 // (generators/parallel_generator.py:185-205).  Rows whose token is not MASK are skipped (conf = -inf).
 // ---------------------------------------------------------------------------------------------------------------
+// M variant (MMaDA-Parallel-M/models/modeling_mmada.py:168-199): the text logits are first combined with the
+// unconditional branch, logits = cond + text_cfg * (uncond - cond), each op rounded to bf16; `unc` == nullptr keeps
+// the A behaviour.  `x0_in` (optional) supplies an externally sampled x0 (float64 Gumbel-max, text_temperature > 0).
+MM_DEVICE float text_cfg_combine(float c, float u, float s) { return bfround(c + bfround(s * bfround(u - c))); }
+
+template <bool CFG>
 __global__ __launch_bounds__(TB) void text_row_stats_kernel(const bf16_t* __restrict__ logits,
-                                                            const bf16_t* __restrict__ noisy, int T, int V, int ld,
+                                                            const bf16_t* __restrict__ noisy,
+                                                            const bf16_t* __restrict__ unc, float text_cfg,
+                                                            const int32_t* __restrict__ x0_in, int T, int V, int ld,
                                                             const int64_t* __restrict__ ids, int L, int text_start,
                                                             int mask_id, double* __restrict__ conf_out,
                                                             int32_t* __restrict__ x0_out) {
@@ -38,34 +46,40 @@ __global__ __launch_bounds__(TB) void text_row_stats_kernel(const bf16_t* __rest
     }
     const bf16_t* lrow = logits + (size_t)row * ld;
     const bf16_t* arow = noisy ? noisy + (size_t)row * ld : lrow;
+    const bf16_t* urow = CFG ? unc + (size_t)row * ld : nullptr;
     const int nchunk = V >> 3;
+    // value of logit i of the (possibly CFG-combined) row
+    auto lval = [&](uint32_t cbits, uint32_t ubits) -> float {
+        const float c = __uint_as_float(cbits);
+        if constexpr (CFG) return text_cfg_combine(c, __uint_as_float(ubits), text_cfg);
+        return c;
+    };
 
     // pass 1: first-index argmax of arow, max of lrow
     float best = -INFINITY, lmax = -INFINITY;
     int bidx = 0x7fffffff;
     for (int c = tid; c < nchunk; c += TB) {
-        const u32x4 av = ((const u32x4*)arow)[c];
+        const u32x4 lv = ((const u32x4*)lrow)[c];
+        u32x4 uv = lv;
+        if constexpr (CFG) uv = ((const u32x4*)urow)[c];
+        u32x4 av = lv;
+        if (noisy) av = ((const u32x4*)arow)[c];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float lo = __uint_as_float(av[j] << 16), hi = __uint_as_float(av[j] & 0xffff0000u);
+            const float l0 = lval(lv[j] << 16, uv[j] << 16), l1 = lval(lv[j] & 0xffff0000u, uv[j] & 0xffff0000u);
+            lmax = fmaxf(lmax, fmaxf(l0, l1));
+            const float lo = noisy ? __uint_as_float(av[j] << 16) : l0;
+            const float hi = noisy ? __uint_as_float(av[j] & 0xffff0000u) : l1;
             if (lo > best) { best = lo; bidx = c * 8 + 2 * j; }
             if (hi > best) { best = hi; bidx = c * 8 + 2 * j + 1; }
         }
-        if (noisy) {
-            const u32x4 lv = ((const u32x4*)lrow)[c];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                lmax = fmaxf(lmax, __uint_as_float(lv[j] << 16));
-                lmax = fmaxf(lmax, __uint_as_float(lv[j] & 0xffff0000u));
-            }
-        }
     }
     for (int i = (nchunk << 3) + tid; i < V; i += TB) {  // tail (V % 8)
-        const float a = bf2f(arow[i]);
+        const float l = lval((uint32_t)lrow[i] << 16, CFG ? (uint32_t)urow[i] << 16 : 0u);
+        lmax = fmaxf(lmax, l);
+        const float a = noisy ? bf2f(arow[i]) : l;
         if (a > best || (a == best && i < bidx)) { best = a; bidx = i; }
-        if (noisy) lmax = fmaxf(lmax, bf2f(lrow[i]));
     }
-    if (!noisy) lmax = best;
     // wave reduce (value desc, index asc)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
@@ -83,26 +97,31 @@ __global__ __launch_bounds__(TB) void text_row_stats_kernel(const bf16_t* __rest
         lmax = fmaxf(lmax, s_max[w]);
     }
     if (bidx == 0x7fffffff) bidx = 0;  // all -inf / NaN row
+    if (x0_in) bidx = x0_in[row];
 
     // pass 2: sum exp(l - max) in fp64 (F.softmax(text_logits.to(torch.float64)), :193)
     const double dmax = (double)lmax;
     double sum = 0.0;
     for (int c = tid; c < nchunk; c += TB) {
         const u32x4 lv = ((const u32x4*)lrow)[c];
+        u32x4 uv = lv;
+        if constexpr (CFG) uv = ((const u32x4*)urow)[c];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            sum += exp((double)__uint_as_float(lv[j] << 16) - dmax);
-            sum += exp((double)__uint_as_float(lv[j] & 0xffff0000u) - dmax);
+            sum += exp((double)lval(lv[j] << 16, uv[j] << 16) - dmax);
+            sum += exp((double)lval(lv[j] & 0xffff0000u, uv[j] & 0xffff0000u) - dmax);
         }
     }
-    for (int i = (nchunk << 3) + tid; i < V; i += TB) sum += exp((double)bf2f(lrow[i]) - dmax);
+    for (int i = (nchunk << 3) + tid; i < V; i += TB)
+        sum += exp((double)lval((uint32_t)lrow[i] << 16, CFG ? (uint32_t)urow[i] << 16 : 0u) - dmax);
     sum = wave_sum_d(sum);
     if (lane == 0) s_sum[wave] = sum;
     __syncthreads();
     if (tid == 0) {
         double tot = 0.0;
         for (int w = 0; w < TB / 64; ++w) tot += s_sum[w];
-        conf_out[row] = exp((double)bf2f(lrow[bidx]) - dmax) / tot;
+        const float lsel = lval((uint32_t)lrow[bidx] << 16, CFG ? (uint32_t)urow[bidx] << 16 : 0u);
+        conf_out[row] = exp((double)lsel - dmax) / tot;
         x0_out[row] = bidx;
     }
 }
@@ -142,6 +161,12 @@ MM_DEVICE float cfg_combine(float c, float ut, float ui, bool use_t, bool use_i,
     return l;
 }
 
+// M variant (modeling_mmada.py:216): image_logits = (1 + image_cfg) * cond - image_cfg * uncond, bf16 per op.
+MM_DEVICE float cfg_combine_m(float c, float u, float one_plus, float s) {
+    return bfround(bfround(one_plus * c) - bfround(s * u));
+}
+
+template <bool MVAR>
 __global__ __launch_bounds__(TB) void image_probs_kernel(const bf16_t* __restrict__ cond, const bf16_t* __restrict__ ut,
                                                          const bf16_t* __restrict__ ui, int CB, float cfg_scale,
                                                          float cfg_img, bf16_t* __restrict__ probs_out,
@@ -153,7 +178,7 @@ __global__ __launch_bounds__(TB) void image_probs_kernel(const bf16_t* __restric
     __shared__ double s_d[TB / 64];
     __shared__ int s_i[TB / 64];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const bool use_t = cfg_scale != 0.0f && ut != nullptr, use_i = cfg_img != 0.0f && ui != nullptr;
+    const bool use_t = MVAR || (cfg_scale != 0.0f && ut != nullptr), use_i = !MVAR && cfg_img != 0.0f && ui != nullptr;
     const bf16_t* crow = cond + (size_t)row * CB;
     const bf16_t* trow = use_t ? ut + (size_t)row * CB : crow;
     const bf16_t* irow = use_i ? ui + (size_t)row * CB : crow;
@@ -167,10 +192,17 @@ __global__ __launch_bounds__(TB) void image_probs_kernel(const bf16_t* __restric
         if (use_i) iv = ((const u32x4*)irow)[c];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float l0 = cfg_combine(__uint_as_float(cv[j] << 16), __uint_as_float(tv[j] << 16),
-                                         __uint_as_float(iv[j] << 16), use_t, use_i, cfg_scale, cfg_img);
-            const float l1 = cfg_combine(__uint_as_float(cv[j] & 0xffff0000u), __uint_as_float(tv[j] & 0xffff0000u),
-                                         __uint_as_float(iv[j] & 0xffff0000u), use_t, use_i, cfg_scale, cfg_img);
+            float l0, l1;
+            if constexpr (MVAR) {  // ut = uncond branch, cfg_scale = image_cfg, cfg_img = 1 + image_cfg (host-computed)
+                l0 = cfg_combine_m(__uint_as_float(cv[j] << 16), __uint_as_float(tv[j] << 16), cfg_img, cfg_scale);
+                l1 = cfg_combine_m(__uint_as_float(cv[j] & 0xffff0000u), __uint_as_float(tv[j] & 0xffff0000u), cfg_img,
+                                   cfg_scale);
+            } else {
+                l0 = cfg_combine(__uint_as_float(cv[j] << 16), __uint_as_float(tv[j] << 16),
+                                 __uint_as_float(iv[j] << 16), use_t, use_i, cfg_scale, cfg_img);
+                l1 = cfg_combine(__uint_as_float(cv[j] & 0xffff0000u), __uint_as_float(tv[j] & 0xffff0000u),
+                                 __uint_as_float(iv[j] & 0xffff0000u), use_t, use_i, cfg_scale, cfg_img);
+            }
             e[c * 8 + 2 * j] = l0;
             e[c * 8 + 2 * j + 1] = l1;
             mx = fmaxf(mx, fmaxf(l0, l1));
@@ -230,6 +262,10 @@ __global__ __launch_bounds__(TB) void image_probs_kernel(const bf16_t* __restric
 // Image step part 2: keep known tokens, confidence, stable lowest-k re-mask, write back
 // (generators/parallel_generator.py:221-233, 304-344; mask_by_random_topk :23-70).
 // ---------------------------------------------------------------------------------------------------------------
+// MVAR (MMaDA-Parallel-M/models/sampling.py:31-36 + modeling_mmada.py:225-241): no clamp of known ids,
+// confidence = log(clamp(p, 1e-20)) + temperature * gumbel (caller supplies the gumbel tensor), and the re-mask rule is
+// the cut-off compare  confidence < sorted[mask_len]  (ties with the cut-off value are NOT masked).
+template <bool MVAR>
 __global__ __launch_bounds__(1024) void image_commit_kernel(int64_t* __restrict__ ids, int L,
                                                             const int32_t* __restrict__ pos_map, int N,
                                                             const int32_t* __restrict__ sampled_in,
@@ -250,15 +286,21 @@ __global__ __launch_bounds__(1024) void image_commit_kernel(int64_t* __restrict_
         const long long tok = row[pos_map[n]];
         const bool unknown = tok == (long long)mask_id;
         long long vq = tok - text_vocab;
-        vq = vq < 0 ? 0 : (vq > codebook - 1 ? codebook - 1 : vq);
+        if constexpr (!MVAR) vq = vq < 0 ? 0 : (vq > codebook - 1 ? codebook - 1 : vq);
         int sidx = unknown ? sampled_in[(size_t)b * N + n] : (int)vq;
-        sidx = sidx < 0 ? 0 : (sidx > codebook - 1 ? codebook - 1 : sidx);
+        if constexpr (!MVAR) sidx = sidx < 0 ? 0 : (sidx > codebook - 1 ? codebook - 1 : sidx);
         // selected_probs = unknown ? probs[sampled] : finfo(bf16).max  (:311-315)
         const float p = unknown ? bf2f(p_in[(size_t)b * N + n]) : bf2f((bf16_t)0x7f7f);
         // confidence = log(probs + 1e-10) + temperature * noise, each op rounded to bf16 (:36); torch rounds the
         // scalar of a bf16 `tensor + scalar` to bf16 first, while `scalar * tensor` multiplies in fp32
-        float c = bfround((float)log((double)bfround(p + bfround(1e-10f))));
-        if (noise) c = bfround(c + bfround(remask_temp * bf2f(noise[(size_t)b * N + n])));
+        float c;
+        if constexpr (MVAR) {
+            c = bfround((float)log((double)(p < 1e-20f ? bfround(1e-20f) : p)));  // log(t.clamp(min=1e-20)) in bf16
+            c = bfround(c + bfround(remask_temp * bf2f(noise[(size_t)b * N + n])));
+        } else {
+            c = bfround((float)log((double)bfround(p + bfround(1e-10f))));
+            if (noise) c = bfround(c + bfround(remask_temp * bf2f(noise[(size_t)b * N + n])));
+        }
         conf[n] = c;
         samp[n] = sidx;
         my_unknown += unknown;
@@ -272,25 +314,36 @@ __global__ __launch_bounds__(1024) void image_commit_kernel(int64_t* __restrict_
     for (int n = tid; n < N; n += blockDim.x) {
         const float c = conf[n];
         int rank = 0;
-        for (int j = 0; j < N; ++j) {
-            const float cj = conf[j];
-            rank += (cj < c) || (cj == c && j < n);
+        if constexpr (MVAR) {
+            // conf < sorted[k]  <=>  at most k elements are <= conf (its own tie class sits below position k)
+            for (int j = 0; j < N; ++j) rank += conf[j] <= c;
+            row[pos_map[n]] = (rank <= k) ? (int64_t)mask_id : (int64_t)((long long)samp[n] + text_vocab);
+        } else {
+            for (int j = 0; j < N; ++j) {
+                const float cj = conf[j];
+                rank += (cj < c) || (cj == c && j < n);
+            }
+            row[pos_map[n]] = (rank < k) ? (int64_t)mask_id : (int64_t)(samp[n] + text_vocab);
         }
-        row[pos_map[n]] = (rank < k) ? (int64_t)mask_id : (int64_t)(samp[n] + text_vocab);
     }
 }
 
 }  // namespace
 
-int launch_text_select(const bf16_t* logits, const bf16_t* noisy, int B, int T, int V, int ld, int64_t* ids, int L,
-                       int text_start, const int32_t* k, void* scratch, int mask_id, hipStream_t s) {
+int launch_text_select(const bf16_t* logits, const bf16_t* noisy, const bf16_t* unc, float text_cfg, const int32_t* x0_in,
+                       int B, int T, int V, int ld, int64_t* ids, int L, int text_start, const int32_t* k, void* scratch,
+                       int mask_id, hipStream_t s) {
     if (B <= 0 || T <= 0) return 0;
     if (ld % 8) return mm_fail("text_select: ld_logits must be a multiple of 8");
     if (T > 8192) return mm_fail("text_select: T=%d too large", T);
     double* conf = (double*)scratch;
     int32_t* x0 = (int32_t*)((char*)scratch + (size_t)B * T * 8);
-    hipLaunchKernelGGL(text_row_stats_kernel, dim3(B * T), dim3(TB), 0, s, logits, noisy, T, V, ld, ids, L, text_start,
-                       mask_id, conf, x0);
+    if (unc)
+        hipLaunchKernelGGL(text_row_stats_kernel<true>, dim3(B * T), dim3(TB), 0, s, logits, noisy, unc, text_cfg, x0_in, T,
+                           V, ld, ids, L, text_start, mask_id, conf, x0);
+    else
+        hipLaunchKernelGGL(text_row_stats_kernel<false>, dim3(B * T), dim3(TB), 0, s, logits, noisy, unc, text_cfg, x0_in,
+                           T, V, ld, ids, L, text_start, mask_id, conf, x0);
     MM_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(text_commit_kernel, dim3(B), dim3(TB), (size_t)T * 8, s, conf, x0, T, ids, L, text_start, k);
     MM_CHECK_HIP(hipGetLastError());
@@ -298,28 +351,39 @@ int launch_text_select(const bf16_t* logits, const bf16_t* noisy, int B, int T, 
 }
 
 int launch_image_probs(const bf16_t* cond, const bf16_t* ut, const bf16_t* ui, int B, int N, int CB, float cfg_scale,
-                       float cfg_img, bf16_t* probs_out, int32_t* argmax_out, bf16_t* pmax_out, hipStream_t s) {
+                       float cfg_img, bf16_t* probs_out, int32_t* argmax_out, bf16_t* pmax_out, int mvar, hipStream_t s) {
     if (B * N <= 0) return 0;
     if (CB % 8 || CB > 16384) return mm_fail("image_probs: codebook=%d must be a multiple of 8 and <= 16384", CB);
     static bool attr_set = false;
     if (!attr_set) {
-        MM_CHECK_HIP(hipFuncSetAttribute((const void*)image_probs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         16384 * 4));
+        MM_CHECK_HIP(hipFuncSetAttribute((const void*)image_probs_kernel<false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4));
+        MM_CHECK_HIP(hipFuncSetAttribute((const void*)image_probs_kernel<true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4));
         attr_set = true;
     }
-    hipLaunchKernelGGL(image_probs_kernel, dim3(B * N), dim3(TB), (size_t)CB * 4, s, cond, ut, ui, CB, cfg_scale, cfg_img,
-                       probs_out, argmax_out, pmax_out);
+    if (mvar)
+        hipLaunchKernelGGL(image_probs_kernel<true>, dim3(B * N), dim3(TB), (size_t)CB * 4, s, cond, ut, ui, CB, cfg_scale,
+                           cfg_img, probs_out, argmax_out, pmax_out);
+    else
+        hipLaunchKernelGGL(image_probs_kernel<false>, dim3(B * N), dim3(TB), (size_t)CB * 4, s, cond, ut, ui, CB, cfg_scale,
+                           cfg_img, probs_out, argmax_out, pmax_out);
     MM_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_image_commit(int64_t* ids, int B, int L, const int32_t* pos_map, int N, const int32_t* sampled_in,
                         const bf16_t* p_in, const bf16_t* noise, float remask_temp, const int32_t* mask_len_sched,
-                        int mask_id, int text_vocab, int codebook, hipStream_t s) {
+                        int mask_id, int text_vocab, int codebook, int mvar, hipStream_t s) {
     if (B <= 0 || N <= 0) return 0;
     if (N > 8192) return mm_fail("image_commit: N=%d too large", N);
-    hipLaunchKernelGGL(image_commit_kernel, dim3(B), dim3(1024), (size_t)N * 8, s, ids, L, pos_map, N, sampled_in, p_in,
-                       noise, remask_temp, mask_len_sched, mask_id, text_vocab, codebook);
+    if (mvar) {
+        if (!noise) return mm_fail("image_commit (M variant): the gumbel tensor is required");
+        hipLaunchKernelGGL(image_commit_kernel<true>, dim3(B), dim3(1024), (size_t)N * 8, s, ids, L, pos_map, N, sampled_in,
+                           p_in, noise, remask_temp, mask_len_sched, mask_id, text_vocab, codebook);
+    } else
+        hipLaunchKernelGGL(image_commit_kernel<false>, dim3(B), dim3(1024), (size_t)N * 8, s, ids, L, pos_map, N, sampled_in,
+                           p_in, noise, remask_temp, mask_len_sched, mask_id, text_vocab, codebook);
     MM_CHECK_HIP(hipGetLastError());
     return 0;
 }

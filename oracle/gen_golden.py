@@ -170,6 +170,89 @@ def gen_e2e():
     print(f"e2e_tiny: {len(calls)} model calls; vq[:8]={vq[:8]}")
 
 
+# ---- M variant: MMadaModelLM.interleave_generate driven by stub logits and per-call seeded RNG draws ------------------
+M_REF = "/root/reference/MMaDA-Parallel-M"
+M_CASES = {
+    "m_both": dict(text_cfg=1.5, image_cfg=3.5, text_steps=8, image_steps=4, image_temperature=1.0, text_temperature=0.0),
+    "m_img": dict(text_cfg=0.0, image_cfg=2.0, text_steps=7, image_steps=7, image_temperature=0.5, text_temperature=0.0),
+    "m_noisy": dict(text_cfg=0.7, image_cfg=3.5, text_steps=6, image_steps=3, image_temperature=1.0, text_temperature=0.8),
+}
+M_SHAPE = dict(prompt=6, N=16, T=16, text_vocab=2048, CB=512, soi=2040, eoi=2041, bos=2042, mask_id=126336)
+
+
+def gen_m_traj():
+    import importlib
+    import types
+    from unittest import mock
+
+    from oracle.interleave_oracle import SeededRng
+
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [M_REF + "/models"]
+    saved = {k: sys.modules.get(k) for k in ("models",)}
+    sys.modules["models"] = pkg  # the package __init__ imports files that do not exist: bypass it
+    mm = importlib.import_module("models.modeling_mmada")
+    sh = M_SHAPE
+    V = sh["text_vocab"] + sh["CB"]
+    out = {}
+    for ci, (name, kw) in enumerate(M_CASES.items()):
+        seed = 31 + ci
+        g = torch.Generator().manual_seed(seed)
+        inp = torch.randint(0, 2000, (sh["prompt"],), generator=g)
+        unc = torch.randint(0, 2000, (sh["prompt"],), generator=g)
+        calls = []
+        n = [0]
+
+        class FakeSelf:
+            config = SimpleNamespace(mask_token_id=sh["mask_id"])
+
+            def __call__(self, ids):
+                n[0] += 1
+                calls.append(ids.clone())
+                return SimpleNamespace(logits=stub_logits(seed, n[0], ids.shape[0], ids.shape[1], V))
+
+        class Tok:
+            bos_token_id = sh["bos"]
+
+            def __len__(self):
+                return sh["text_vocab"]
+
+        cfgobj = SimpleNamespace(model=SimpleNamespace(mmada=SimpleNamespace(num_vq_tokens=sh["N"], codebook_size=sh["CB"])),
+                                 dataset=SimpleNamespace(preprocessing=SimpleNamespace(max_seq_length=sh["T"])))
+        rng = SeededRng(seed)
+        real_uniform = torch.Tensor.uniform_
+
+        def fake_multinomial(inp_, num, replacement=False, *, generator=None):
+            return rng.multinomial(inp_)[:, None]
+
+        def fake_uniform(self, a=0, b=1, *, generator=None):
+            return real_uniform(self, a, b, generator=rng._g())
+
+        def fake_rand_like(t, dtype=None, **_):
+            return rng.rand_f64(t.shape)
+
+        with mock.patch.object(torch, "multinomial", fake_multinomial), \
+                mock.patch.object(torch.Tensor, "uniform_", fake_uniform), \
+                mock.patch.object(torch, "rand_like", fake_rand_like), \
+                contextlib.redirect_stdout(io.StringIO()):
+            img, text = mm.MMadaModelLM.interleave_generate(
+                FakeSelf(), inp, unc, reserved_token_mapping={"<|soi|>": sh["soi"], "<|eoi|>": sh["eoi"]}, config=cfgobj,
+                uni_prompting=SimpleNamespace(text_tokenizer=Tok()), generator=None, **kw)
+        out[name + "_calls"] = torch.stack(calls, 0).numpy()   # [steps, 2, L]
+        out[name + "_img"] = img.numpy()
+        out[name + "_text"] = text.numpy()
+        out[name + "_seed"] = np.array(seed)
+        out[name + "_inp"] = inp.numpy()
+        out[name + "_unc"] = unc.numpy()
+        print(f"m_traj[{name}]: {len(calls)} forwards, L={calls[0].shape[1]}")
+    np.savez_compressed(os.path.join(OUT, "m_traj.npz"), **out)
+    for k, v in saved.items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+
+
 def gen_tables():
     b = torch.arange(0, 0x7f80, dtype=torch.int32).to(torch.int16)
     np.save(os.path.join(OUT, "logconf_table.npy"), torch.log(b.view(torch.bfloat16) + 1e-10).view(torch.int16).numpy())
@@ -180,6 +263,7 @@ if __name__ == "__main__":
         sys.exit("reference not mounted at " + REF)
     os.makedirs(OUT, exist_ok=True)
     gen_tables()
+    gen_m_traj()
     gen_sampler_traj()
     gen_forward()
     gen_e2e()

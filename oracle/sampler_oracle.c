@@ -201,6 +201,121 @@ void oracle_image_commit(int64_t* ids, int B, int L, const int32_t* pos_map, int
     free(masking);
 }
 
+/* ==== M variant: MMaDA-Parallel-M/models/modeling_mmada.py:117-248, models/sampling.py:31-36 ================== */
+
+/* text step (:179-207): logits = cond + text_cfg * (uncond - cond) (bf16 per op), then the A text step on it;
+ * x0_in != NULL replaces the argmax (float64 Gumbel-max computed by the caller, :181-182). */
+void oracle_text_select_cfg(const uint16_t* cond, const uint16_t* unc, float text_cfg, const int32_t* x0_in, int B, int T,
+                            int V, int ld, int64_t* ids, int L, int text_start, const int32_t* k, int mask_id,
+                            double* conf_out, int32_t* x0_out) {
+    uint16_t* comb = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)B * T * ld);
+    for (size_t r = 0; r < (size_t)B * T; ++r)
+        for (int i = 0; i < V; ++i) {
+            const float c = bf2f(cond[r * ld + i]), u = bf2f(unc[r * ld + i]);
+            comb[r * ld + i] = f2bf(c + bfround(text_cfg * bfround(u - c)));
+        }
+    if (!x0_in) {
+        oracle_text_select(comb, NULL, B, T, V, ld, ids, L, text_start, k, mask_id, conf_out, x0_out);
+    } else {
+        /* same as oracle_text_select with x0 given: confidence = softmax_f64(comb)[x0] */
+        conf_idx* ci = (conf_idx*)malloc(sizeof(conf_idx) * (size_t)T);
+        for (int b = 0; b < B; ++b) {
+            for (int t = 0; t < T; ++t) {
+                const size_t row = (size_t)b * T + t;
+                const uint16_t* l = comb + row * ld;
+                const int masked = ids[(size_t)b * L + text_start + t] == (int64_t)mask_id;
+                double mx = (double)bf2f(l[0]);
+                for (int i = 1; i < V; ++i) if ((double)bf2f(l[i]) > mx) mx = (double)bf2f(l[i]);
+                double sum = 0.0;
+                for (int i = 0; i < V; ++i) sum += exp((double)bf2f(l[i]) - mx);
+                const int x0 = x0_in[row];
+                ci[t].c = masked ? exp((double)bf2f(l[x0]) - mx) / sum : -INFINITY;
+                ci[t].idx = t;
+                if (conf_out) conf_out[row] = ci[t].c;
+                if (x0_out) x0_out[row] = masked ? x0 : 0;
+            }
+            if (k[b] > 0) {
+                qsort(ci, (size_t)T, sizeof(conf_idx), cmp_desc);
+                for (int j = 0; j < k[b] && j < T; ++j)
+                    if (ci[j].c != -INFINITY)
+                        ids[(size_t)b * L + text_start + ci[j].idx] = (int64_t)x0_in[(size_t)b * T + ci[j].idx];
+            }
+        }
+        free(ci);
+    }
+    free(comb);
+}
+
+/* image logits (:216): (1 + image_cfg) * cond - image_cfg * uncond, bf16 per op; softmax -> bf16 probs */
+void oracle_image_probs_m(const uint16_t* cond, const uint16_t* unc, int B, int N, int CB, float image_cfg,
+                          uint16_t* probs_out, int32_t* argmax_out, uint16_t* pmax_out) {
+    float* lg = (float*)malloc(sizeof(float) * (size_t)CB);
+    float* e = (float*)malloc(sizeof(float) * (size_t)CB);
+    const float one_plus = (float)(1.0 + (double)image_cfg);
+    for (size_t row = 0; row < (size_t)B * N; ++row) {
+        float mx = -INFINITY;
+        for (int i = 0; i < CB; ++i) {
+            const float l = bfround(bfround(one_plus * bf2f(cond[row * CB + i])) - bfround(image_cfg * bf2f(unc[row * CB + i])));
+            lg[i] = l;
+            if (l > mx) mx = l;
+        }
+        double sum = 0.0;
+        for (int i = 0; i < CB; ++i) {
+            e[i] = (float)exp((double)(lg[i] - mx));
+            sum += (double)e[i];
+        }
+        const float fsum = (float)sum;
+        int best = 0;
+        float bp = -1.0f;
+        for (int i = 0; i < CB; ++i) {
+            const uint16_t pb = f2bf(e[i] / fsum);
+            if (probs_out) probs_out[row * CB + i] = pb;
+            if (bf2f(pb) > bp) { bp = bf2f(pb); best = i; }
+        }
+        argmax_out[row] = best;
+        pmax_out[row] = f2bf(bp);
+    }
+    free(lg);
+    free(e);
+}
+
+static int cmp_float_asc(const void* a, const void* b) {
+    const float x = *(const float*)a, y = *(const float*)b;
+    return (x > y) - (x < y);
+}
+
+/* re-mask + write-back (:224-241; sampling.py:31-36): masking = confidence < sorted(confidence)[mask_len] */
+void oracle_image_commit_m(int64_t* ids, int B, int L, const int32_t* pos_map, int N, const int32_t* sampled_in,
+                           const uint16_t* p_in, const uint16_t* gumbel, float remask_temp, int mask_len_sched, int mask_id,
+                           int text_vocab) {
+    float* conf = (float*)malloc(sizeof(float) * (size_t)N);
+    float* sorted = (float*)malloc(sizeof(float) * (size_t)N);
+    int64_t* samp = (int64_t*)malloc(sizeof(int64_t) * (size_t)N);
+    for (int b = 0; b < B; ++b) {
+        int64_t* row = ids + (size_t)b * L;
+        int unknown_count = 0;
+        for (int n = 0; n < N; ++n) {
+            const int64_t tok = row[pos_map[n]];
+            const int unknown = tok == (int64_t)mask_id;
+            samp[n] = unknown ? (int64_t)sampled_in[(size_t)b * N + n] : tok - text_vocab; /* :214,:225 (no clamp) */
+            const float p = unknown ? bf2f(p_in[(size_t)b * N + n]) : bf2f(0x7f7f);         /* :233 */
+            float c = bfround((float)log((double)(p < 1e-20f ? bfround(1e-20f) : p)));      /* log(t.clamp(min=1e-20)) */
+            c = bfround(c + bfround(remask_temp * bf2f(gumbel[(size_t)b * N + n])));
+            conf[n] = sorted[n] = c;
+            unknown_count += unknown;
+        }
+        int k = unknown_count - 1 < mask_len_sched ? unknown_count - 1 : mask_len_sched; /* :234-235 */
+        if (k < 1) k = 1;
+        if (k > N - 1) k = N - 1;
+        qsort(sorted, (size_t)N, sizeof(float), cmp_float_asc);
+        const float cut = sorted[k];
+        for (int n = 0; n < N; ++n) row[pos_map[n]] = conf[n] < cut ? (int64_t)mask_id : samp[n] + text_vocab; /* :239 */
+    }
+    free(conf);
+    free(sorted);
+    free(samp);
+}
+
 /* log-confidence of a single bf16 probability (exposed for the exhaustive 2^15-value table test) */
 uint16_t oracle_log_conf(uint16_t p_bits) {
     return f2bf((float)log((double)bfround(bf2f(p_bits) + bfround(1e-10f))));

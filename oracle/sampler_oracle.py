@@ -86,3 +86,38 @@ def lfq_gather(idx, nbits):
     out = torch.empty((B, nbits, N), dtype=torch.float32)
     lib().oracle_lfq_gather(_p(idx), B, N, nbits, _p(out))
     return out
+
+
+# ---- M variant (MMaDA-Parallel-M/models/modeling_mmada.py:117-248) ------------------------------------------------
+def text_select_cfg(cond, unc, text_cfg, ids, text_start, k, x0_in=None, mask_id=126336):
+    B, T, V = cond.shape
+    cb, ub = _bits(cond), _bits(unc)
+    ids = ids.detach().to("cpu", torch.long).clone().contiguous()
+    kk = torch.as_tensor(k, dtype=torch.int32).contiguous()
+    x0i = None if x0_in is None else x0_in.detach().to("cpu", torch.int32).contiguous()
+    conf = torch.empty((B, T), dtype=torch.float64)
+    x0 = torch.empty((B, T), dtype=torch.int32)
+    lib().oracle_text_select_cfg(_p(cb), _p(ub), C.c_float(text_cfg), _p(x0i), B, T, V, V, _p(ids), ids.shape[1],
+                                 text_start, _p(kk), mask_id, _p(conf), _p(x0))
+    return ids, conf, x0
+
+
+def image_probs_m(cond, unc, image_cfg):
+    B, N, CB = cond.shape
+    cb, ub = _bits(cond), _bits(unc)
+    probs = torch.empty((B, N, CB), dtype=torch.int16)
+    am = torch.empty((B, N), dtype=torch.int32)
+    pm = torch.empty((B, N), dtype=torch.int16)
+    lib().oracle_image_probs_m(_p(cb), _p(ub), B, N, CB, C.c_float(image_cfg), _p(probs), _p(am), _p(pm))
+    return am, pm.view(torch.bfloat16), probs.view(torch.bfloat16)
+
+
+def image_commit_m(ids, pos_map, sampled, p_sel, gumbel, remask_temp, mask_len_sched, mask_id=126336, text_vocab=126356):
+    ids = ids.detach().to("cpu", torch.long).clone().contiguous()
+    B, L = ids.shape
+    pm = torch.as_tensor(pos_map, dtype=torch.int32).cpu().contiguous()
+    s = sampled.detach().to("cpu", torch.int32).contiguous()
+    pb, gb = _bits(p_sel), _bits(gumbel)
+    lib().oracle_image_commit_m(_p(ids), B, L, _p(pm), pm.numel(), _p(s), _p(pb), _p(gb), C.c_float(remask_temp),
+                                int(mask_len_sched), mask_id, text_vocab)
+    return ids

@@ -46,3 +46,10 @@ def tiny_sd():
     if "tiny" not in _SD:
         _SD["tiny"] = synth.synthetic_state_dict(synth.CFG_TINY, seed=0)
     return _SD["tiny"]
+
+M_CASES = {
+    "m_both": dict(text_cfg=1.5, image_cfg=3.5, text_steps=8, image_steps=4, image_temperature=1.0, text_temperature=0.0),
+    "m_img": dict(text_cfg=0.0, image_cfg=2.0, text_steps=7, image_steps=7, image_temperature=0.5, text_temperature=0.0),
+    "m_noisy": dict(text_cfg=0.7, image_cfg=3.5, text_steps=6, image_steps=3, image_temperature=1.0, text_temperature=0.8),
+}
+M_SHAPE = dict(prompt=6, N=16, T=16, text_vocab=2048, CB=512, soi=2040, eoi=2041, bos=2042, mask_id=126336)

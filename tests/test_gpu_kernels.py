@@ -270,3 +270,73 @@ def test_lfq_gather(handle):
     outb = torch.empty(2, 13, 1024, dtype=torch.bfloat16, device=DEV)
     abi.check(abi.lib().mmada_lfq_gather(handle, idx_d.data_ptr(), 2, 1024, 13, 0, outb.data_ptr(), st()), "lfq")
     assert torch.equal(outb.cpu().float(), so.lfq_gather(idx, 13))
+
+
+# ---------------------------------------------------------------------------------------------------- M-variant kernels
+@pytest.mark.parametrize("B,T,V,k,cfg,with_x0", [(1, 16, 2560, [3], 1.5, False), (2, 32, 134656, [4, 9], 0.7, False),
+                                                 (1, 24, 4100, [24], 0.0, False), (2, 16, 2560, [5, 2], 2.3, True)])
+def test_text_select_cfg_bit_exact(handle, B, T, V, k, cfg, with_x0):
+    from oracle import sampler_oracle as so
+
+    L, ts = T + 12, 7
+    ld = (V + 7) // 8 * 8
+    cond, ids = _text_inputs(B, T, V, L, ts, seed=3 * T + V)
+    unc = (cond.float() + torch.randn(B, T, V, generator=torch.Generator().manual_seed(V)) * 0.7).to(torch.bfloat16)
+    x0_in = torch.randint(0, V, (B, T), generator=torch.Generator().manual_seed(1), dtype=torch.int32) if with_x0 else None
+    cp, up = torch.zeros(B, T, ld, dtype=torch.bfloat16), torch.zeros(B, T, ld, dtype=torch.bfloat16)
+    cp[..., :V], up[..., :V] = cond, unc
+    c_d, u_d, ids_d = cp.to(DEV), up.to(DEV), ids.to(DEV)
+    x0_d = x0_in.to(DEV) if with_x0 else None
+    k_d = torch.tensor(k, dtype=torch.int32, device=DEV)
+    scratch = torch.empty(B * T * 16, dtype=torch.uint8, device=DEV)
+    abi.check(abi.lib().mmada_text_select_cfg(handle, c_d.data_ptr(), u_d.data_ptr(), cfg, abi.ptr(x0_d), B, T, V, ld,
+                                              ids_d.data_ptr(), L, ts, k_d.data_ptr(), scratch.data_ptr(), st()), "text_cfg")
+    ref, conf_ref, x0_ref = so.text_select_cfg(cond, unc, cfg, ids, ts, k, x0_in=x0_in)
+    assert torch.equal(ids_d.cpu(), ref)
+    conf = scratch[: B * T * 8].view(torch.float64).cpu().view(B, T)
+    m = torch.isfinite(conf_ref)
+    assert torch.equal(torch.isfinite(conf), m) and torch.allclose(conf[m], conf_ref[m], rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("B,N,CB,cfg", [(1, 64, 8192, 3.5), (2, 40, 512, 2.0), (1, 16, 8192, 0.3)])
+def test_image_probs_m_bit_exact(handle, B, N, CB, cfg):
+    from oracle import sampler_oracle as so
+
+    g = torch.Generator().manual_seed(N * CB)
+    c = (torch.randn(B, N, CB, generator=g) * 1.5).to(torch.bfloat16)
+    u = (c.float() + torch.randn(B, N, CB, generator=g) * 0.5).to(torch.bfloat16)
+    c_d, u_d = c.to(DEV), u.to(DEV)
+    probs = torch.empty(B, N, CB, dtype=torch.bfloat16, device=DEV)
+    am = torch.empty(B, N, dtype=torch.int32, device=DEV)
+    pm = torch.empty(B, N, dtype=torch.bfloat16, device=DEV)
+    abi.check(abi.lib().mmada_image_probs_m(handle, c_d.data_ptr(), u_d.data_ptr(), B, N, CB, cfg, probs.data_ptr(),
+                                            am.data_ptr(), pm.data_ptr(), st()), "image_probs_m")
+    am_r, pm_r, pr_r = so.image_probs_m(c, u, cfg)
+    assert torch.equal(am.cpu(), am_r) and torch.equal(bits(pm), bits(pm_r)) and torch.equal(bits(probs), bits(pr_r))
+
+
+@pytest.mark.parametrize("known", [0, 100, 255])
+def test_image_commit_m_bit_exact(handle, known):
+    from oracle import sampler_oracle as so
+
+    g = torch.Generator().manual_seed(known + 9)
+    B, N, L, tv = 2, 256, 300, 2048
+    pos = torch.arange(20, 20 + N, dtype=torch.int32)
+    ids = torch.randint(0, 1000, (B, L), generator=g)
+    for b in range(B):
+        ids[b, 20:20 + N] = synth.MASK
+        kn = torch.randperm(N, generator=g)[:known] + 20
+        ids[b, kn] = tv + torch.randint(0, 512, (known,), generator=g)
+    sampled = torch.randint(0, 512, (B, N), generator=g, dtype=torch.int32)
+    p = (torch.randint(0, 30, (B, N), generator=g).float() / 2048).to(torch.bfloat16)     # includes p == 0, heavy ties
+    gum = (-torch.log(-torch.log(torch.rand(B, N, generator=g).clamp(min=1e-20)))).to(torch.bfloat16)
+    pos_d, s_d, p_d, g_d = pos.to(DEV), sampled.to(DEV), p.to(DEV), gum.to(DEV)
+    for temp in (0.0, 0.61):
+        for mlen in (-1, 1, 40, N + 3):
+            ids_d = ids.to(DEV)
+            ml = torch.tensor([mlen], dtype=torch.int32, device=DEV)
+            abi.check(abi.lib().mmada_image_commit_m(handle, ids_d.data_ptr(), B, L, pos_d.data_ptr(), N, s_d.data_ptr(),
+                                                     p_d.data_ptr(), g_d.data_ptr(), temp, ml.data_ptr(), tv, st()),
+                      "image_commit_m")
+            ref = so.image_commit_m(ids, pos, sampled, p, gum, temp, mlen, text_vocab=tv)
+            assert torch.equal(ids_d.cpu(), ref), f"known={known} temp={temp} mlen={mlen}"

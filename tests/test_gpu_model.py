@@ -378,3 +378,48 @@ def test_microbatched_overlap_path_matches_single_context(tiny_model, monkeypatc
         tiny_model.forward_body(ids[:1])  # back to the single-context state for the other tests
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------- M variant: interleave_generate
+from helpers import M_CASES, M_SHAPE  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(M_CASES))
+def test_m_interleave_stub_trajectory_bit_exact(tiny_model, name):
+    """interleave_generate on stub logits with the reference's (per-call seeded) random draws replayed: the ids of
+    every batch-2 forward and the returned image / text ids must equal the reference's (tests/golden/m_traj.npz)."""
+    from types import SimpleNamespace
+
+    from mmada_parallel_amd import interleave_generate
+    from oracle.interleave_oracle import SeededRng
+
+    z = np.load(os.path.join(GOLDEN, "m_traj.npz"))
+    sh, kw = M_SHAPE, dict(M_CASES[name])
+    seed = int(z[name + "_seed"])
+    V = sh["text_vocab"] + sh["CB"]
+    stub = _stubbed(tiny_model, seed, V)
+    calls = []
+
+    def fb(ids):  # the M sampler runs cond+uncond as ONE batch-2 forward: one stub draw per forward
+        stub.n += 1
+        calls.append(ids.cpu().clone())
+        stub._cur = stub_logits(seed, stub.n, ids.shape[0], ids.shape[1], V).to(DEV)
+
+    stub.forward_body = fb
+
+    class Tok:
+        bos_token_id = sh["bos"]
+
+        def __len__(self):
+            return sh["text_vocab"]
+
+    cfgobj = SimpleNamespace(model=SimpleNamespace(mmada=SimpleNamespace(num_vq_tokens=sh["N"], codebook_size=sh["CB"])),
+                             dataset=SimpleNamespace(preprocessing=SimpleNamespace(max_seq_length=sh["T"])))
+    img, text = interleave_generate(stub, torch.from_numpy(z[name + "_inp"]), torch.from_numpy(z[name + "_unc"]),
+                                    reserved_token_mapping={"<|soi|>": sh["soi"], "<|eoi|>": sh["eoi"]}, config=cfgobj,
+                                    uni_prompting=SimpleNamespace(text_tokenizer=Tok()), rng=SeededRng(seed), **kw)
+    got = torch.stack(calls, 0)
+    ref = torch.from_numpy(z[name + "_calls"])
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    assert torch.equal(img.cpu(), torch.from_numpy(z[name + "_img"]))
+    assert torch.equal(text.cpu(), torch.from_numpy(z[name + "_text"]))

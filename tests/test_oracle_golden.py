@@ -144,3 +144,38 @@ def test_lfq_gather_against_reference_formula():
     mask = 2 ** torch.arange(nbits - 1, -1, -1)
     ref = ((idx[..., None] & mask) != 0).float() * 2 - 1  # [B,N,nbits]
     assert torch.equal(so.lfq_gather(idx, nbits), ref.permute(0, 2, 1).contiguous())
+
+
+# ---- M variant: MMadaModelLM.interleave_generate (MMaDA-Parallel-M/models/modeling_mmada.py:117-248) ---------------
+from helpers import M_CASES, M_SHAPE  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(M_CASES))
+def test_m_interleave_trajectory_matches_reference(name):
+    """Oracle restatement of the M sampler vs the ids the reference passed to every forward (stub logits, per-call
+    seeded draws for multinomial / gumbel / float64 text noise)."""
+    from oracle import interleave_oracle as io_
+
+    z = np.load(os.path.join(GOLDEN, "m_traj.npz"))
+    sh, kw = M_SHAPE, dict(M_CASES[name])
+    seed = int(z[name + "_seed"])
+    V = sh["text_vocab"] + sh["CB"]
+    n = [0]
+
+    def model_fn(ids):
+        n[0] += 1
+        return stub_logits(seed, n[0], ids.shape[0], ids.shape[1], V)
+
+    trace = []
+    img, text = io_.generate(model_fn, torch.from_numpy(z[name + "_inp"]), torch.from_numpy(z[name + "_unc"]),
+                             text_cfg=kw["text_cfg"], image_cfg=kw["image_cfg"], text_steps=kw["text_steps"],
+                             image_steps=kw["image_steps"], soi=sh["soi"], eoi=sh["eoi"], bos=sh["bos"],
+                             mask_id=sh["mask_id"], text_vocab=sh["text_vocab"], num_vq_tokens=sh["N"],
+                             codebook_size=sh["CB"], max_seq_length=sh["T"], image_temperature=kw["image_temperature"],
+                             rng=io_.SeededRng(seed), text_temperature=kw["text_temperature"], trace=trace)
+    got = torch.stack(trace, 0)
+    ref = torch.from_numpy(z[name + "_calls"])
+    assert got.shape == ref.shape
+    assert torch.equal(got, ref), f"first differing forward: {(got != ref).flatten(1).any(1).nonzero()[0].item()}"
+    assert torch.equal(img, torch.from_numpy(z[name + "_img"]))
+    assert torch.equal(text, torch.from_numpy(z[name + "_text"]))
