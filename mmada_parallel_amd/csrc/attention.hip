@@ -29,6 +29,19 @@ constexpr float DEFER_LOG2 = 4.0f;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// 3-input / 2-input fp32 max as single instructions: hipcc wraps fmaxf() on MFMA outputs in canonicalising
+// v_max_f32 x,x (one extra VALU op per score); scores are never signalling NaNs here.
+MM_DEVICE float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+MM_DEVICE float fmax_nc(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 struct AttnArgs {
     const bf16_t* q;
     const bf16_t* k;
@@ -116,12 +129,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             }
         }
         // ---- online softmax (fp32, log2 domain); lane and lane^32 share a query ----
-        float mx = fmaxf(s0[0], s1[0]);
+        float mxa = fmax_nc(s0[0], s1[0]), mxb = fmax_nc(s0[1], s1[1]);  // two chains: shorter dependency depth
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2e;
+        for (int r = 2; r < 16; r += 2) {
+            mxa = max3f(mxa, s0[r], s1[r]);
+            mxb = max3f(mxb, s0[r + 1], s1[r + 1]);
+        }
+        float mx = fmax_nc(mxa, mxb);
+        mx = fmax_nc(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2e;
         if (!__all(mx - m_run <= DEFER_LOG2)) {  // wave-uniform: rescale only when some row's max really grew
-            const float m_new = fmaxf(m_run, mx);
+            const float m_new = fmax_nc(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             l_run *= alpha;
 #pragma unroll
