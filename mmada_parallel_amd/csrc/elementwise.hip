@@ -56,11 +56,48 @@ MM_DEVICE void rmsnorm_row(const bf16_t* __restrict__ xr, const bf16_t* __restri
     }
 }
 
+// d == 512*NCH fast path: the whole row lives in registers (NCH x 16 B per lane, all loads in flight at once), one
+// HBM read + one write per element.  Same arithmetic as rmsnorm_row.
+template <int NCH>
+MM_DEVICE void rmsnorm_row_regs(const bf16_t* __restrict__ xr, const bf16_t* __restrict__ w, bf16_t* __restrict__ outr,
+                                float eps, int lane) {
+    u32x4 v[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) v[i] = ((const u32x4*)xr)[lane + 64 * i];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = __uint_as_float(v[i][j] << 16), hi = __uint_as_float(v[i][j] & 0xffff0000u);
+            ss += lo * lo;
+            ss += hi * hi;
+        }
+    ss = wave_sum(ss);
+    const float var = ss / (float)(NCH * 512);
+    const float rs = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const u32x4 wv = ((const u32x4*)w)[lane + 64 * i];
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = __uint_as_float(v[i][j] << 16), hi = __uint_as_float(v[i][j] & 0xffff0000u);
+            const float wl = __uint_as_float(wv[j] << 16), wh = __uint_as_float(wv[j] & 0xffff0000u);
+            o[j] = pack_bf2(wl * bfround(lo * rs), wh * bfround(hi * rs));
+        }
+        ((u32x4*)outr)[lane + 64 * i] = o;
+    }
+}
+
 __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                       bf16_t* __restrict__ out, int rows, int d, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    rmsnorm_row(x + (size_t)row * d, w, out + (size_t)row * d, d, eps, threadIdx.x & 63);
+    if (d == 4096)
+        rmsnorm_row_regs<8>(x + (size_t)row * d, w, out + (size_t)row * d, eps, threadIdx.x & 63);
+    else
+        rmsnorm_row(x + (size_t)row * d, w, out + (size_t)row * d, d, eps, threadIdx.x & 63);
 }
 
 __global__ __launch_bounds__(256) void rmsnorm_gather_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
@@ -70,7 +107,10 @@ __global__ __launch_bounds__(256) void rmsnorm_gather_kernel(const bf16_t* __res
     if (r >= R) return;
     const int flat = rows[r];
     const int b = flat / L, l = flat - b * L;
-    rmsnorm_row(x + ((size_t)b * Lp + l) * d, w, out + (size_t)r * d, d, eps, threadIdx.x & 63);
+    if (d == 4096)
+        rmsnorm_row_regs<8>(x + ((size_t)b * Lp + l) * d, w, out + (size_t)r * d, eps, threadIdx.x & 63);
+    else
+        rmsnorm_row(x + ((size_t)b * Lp + l) * d, w, out + (size_t)r * d, d, eps, threadIdx.x & 63);
 }
 
 // ---- RoPE table (model/modeling_llada.py:391-397): freqs = seq (x) inv_freq in fp32; sin/cos of the fp32 angle.

@@ -516,6 +516,158 @@ __global__ __launch_bounds__(512, 2) void gemm_pp_kernel(GemmArgs g) {
         }
 }
 
+// Ping-pong with 4 phases per K-tile: R(kk) reads all 12 fragments of one 32-deep half (8 A + 4 B), C(kk) issues the
+// 32 MFMAs of that half over the whole 128x64 wave tile; half as many barriers as gemm_pp_kernel.
+template <int NPH>
+__global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 64, A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wm = grp, wn = wave & 3;
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    constexpr int GN = 4;
+    const int gsize = GN * ntm;
+    const int grp_t = id / gsize, rem = id - grp_t * gsize;
+    const int gn = min(GN, ntn - grp_t * GN);
+    const int mt = rem / gn, nt = grp_t * GN + (rem - (rem / gn) * gn);
+    const int m0 = mt * BM, n0 = nt * BN;
+    const bf16_t* asrc[4];
+    const bf16_t* wsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (wave * 4 + i) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        asrc[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + c * 8;
+        wsrc[i] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw + c * 8;
+    }
+    auto dma = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE_BYTES + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BK), (lptr_t)(base + i * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kt * BK), (lptr_t)(base + A_BYTES + i * 1024), 16, 0, 0);
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    int aoff[8][2], boff[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int row = wm * 128 + mi * 16 + frow;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) aoff[mi][kk] = row * 128 + (((kk * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+    }
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int row = wn * 64 + ni * 16 + frow;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) boff[ni][kk] = A_BYTES + row * 128 + (((kk * 4 + fq) ^ ((row >> 1) & 7)) << 4);
+    }
+    const int nk = g.K / BK;
+    dma(0, 0);
+    PP_VM0();
+    PP_BARRIER();
+    if (NPH == 2 && nk > 1) dma(1, 1);
+    if (grp == 1) PP_BARRIER();
+    if constexpr (NPH == 4) {
+        bf16x8 af[8], bfr[4];
+        auto rd = [&](const char* st, int kk) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = *(const bf16x8*)(st + aoff[i][kk]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bfr[i] = *(const bf16x8*)(st + boff[i][kk]);
+        };
+        auto mma = [&]() {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        };
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* st = smem + (kt & 1) * STAGE_BYTES;
+            if (kt + 1 < nk) dma((kt + 1) & 1, kt + 1);  // R0: next K-tile + fragments of half 0
+            rd(st, 0);
+            PP_LGKM0();
+            PP_BARRIER();
+            mma();  // C0
+            PP_BARRIER();
+            rd(st, 1);  // R1
+            PP_LGKM0();
+            PP_VM0();   // group B: next K-tile must be complete one phase before group A reads it
+            PP_BARRIER();
+            mma();  // C1
+            PP_VM0();
+            PP_BARRIER();
+        }
+    } else {  // NPH == 2: the whole K-tile's 24 fragments are read in one phase, 64 MFMAs in the other.
+        // All 8 waves issue the LDS-DMA of K-tile t+1 in the same global phase (group A at the top of its R(t),
+        // group B at the top of its C(t-1)) and drain it one phase later (A: end of C(t), B: end of R(t)), i.e. one
+        // phase before group A starts reading it.
+        bf16x8 af[8][2], bfr[4][2];
+        for (int kt = 0; kt < nk; ++kt) {
+            const char* st = smem + (kt & 1) * STAGE_BYTES;
+            if (grp == 0 && kt >= 1 && kt + 1 < nk) dma((kt + 1) & 1, kt + 1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) af[i][kk] = *(const bf16x8*)(st + aoff[i][kk]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bfr[i][kk] = *(const bf16x8*)(st + boff[i][kk]);
+            }
+            PP_LGKM0();
+            if (grp == 1) PP_VM0();
+            PP_BARRIER();
+            if (grp == 1 && kt + 2 < nk) dma(kt & 1, kt + 2);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][kk], bfr[j][kk], acc[i][j], 0, 0, 0);
+            if (grp == 0) PP_VM0();
+            PP_BARRIER();
+        }
+    }
+    if (grp == 0) PP_BARRIER();
+    const int mrow0 = m0 + wm * 128 + fq * 4, ncol0 = n0 + wn * 64 + frow;
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mrow0 + mi * 16 + r;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = ncol0 + ni * 16;
+                if (n < g.N) g.C[(size_t)m * g.ldc + n] = f2bf(acc[mi][ni][r]);
+            }
+        }
+}
+
+template <int NPH>
+int launch_pp2(const GemmArgs& g, hipStream_t s) {
+    constexpr int LDS = 2 * 512 * 128;
+    static bool attr_set = false;
+    auto fn = gemm_pp2_kernel<NPH>;
+    if (!attr_set) {
+        MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int ntm = (g.M + 255) / 256, ntn = (g.N + 255) / 256;
+    hipLaunchKernelGGL(fn, dim3(ntm * ntn), dim3(512), LDS, s, g);
+    MM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <bool SETPRIO, int GRPMODE>
 int launch_pp(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = 2 * 512 * 128;
@@ -589,6 +741,8 @@ int launch_gemm_variant(int variant, const GemmArgs& g, hipStream_t s) {
         case 18: return launch_var<256, 256, 64, 4, 2, 2, 2>(g, s);
         case 30: return launch_pp<false, 0>(g, s);
         case 31: return launch_pp<true, 0>(g, s);
+        case 34: return launch_pp2<4>(g, s);
+        case 35: return launch_pp2<2>(g, s);
         case 32: return launch_pp<false, 1>(g, s);
         case 33: return launch_pp<false, 2>(g, s);
         case 20: return launch_big<4, false>(g, s);
