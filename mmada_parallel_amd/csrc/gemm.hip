@@ -60,6 +60,10 @@ MM_DEVICE void tile_coords(int t, int ntm, int ntn, int& mt, int& nt) {
     nt = grp * GN + (rem - mt * gn);
 }
 
+// LDS stages: 3 where 3 x (BM + 256) x 128 B fits in the 160 KiB LDS (BM <= 160), else 2.  A 160-row K-tile is
+// only ~0.7 us of MFMA work, less than an HBM round trip under load, so one tile of look-ahead is not enough there.
+constexpr int stages_for(int bm) { return 3 * (bm + BN) * 128 <= 160 * 1024 ? 3 : 2; }
+
 template <int BM, int WM, int WN>
 struct Tile {
     static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
@@ -67,6 +71,8 @@ struct Tile {
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE_BYTES = A_BYTES + B_BYTES;
     static constexpr int PA_TOTAL = BM / 8;  // 1-KiB LDS-DMA pieces (8 rows x 128 B) of the A tile
     static constexpr int PA = (PA_TOTAL + NWAVES - 1) / NWAVES, PB = BN / 8 / NWAVES;
+    static constexpr int STAGES = stages_for(BM);
+    static constexpr int LDS_BYTES = STAGES * STAGE_BYTES;
 };
 
 // acc += A[m0.., k-tiles k0..k1) · W[n0.., same k-tiles)^T.  Two LDS stages, one raw s_barrier per K-tile:
@@ -106,12 +112,24 @@ MM_DEVICE void mainloop(const GemmArgs& g, char* smem, int m0, int n0, int k0, i
 
     // every wave's LDS reads of the previous tile of this workgroup are done before stage 0 is overwritten
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    // this wave's LDS-DMA pieces per K-tile (the A pieces do not always divide evenly over the 16 waves)
+    const bool extra_a = (T::PA_TOTAL % NWAVES != 0) && (wave < T::PA_TOTAL % NWAVES);
     stage(0, k0);
+    if (T::STAGES == 3 && k0 + 1 < k1) stage(1, k0 + 1);
     for (int kt = k0; kt < k1; ++kt) {
-        const int cur = (kt - k0) & 1;
-        // this wave's pieces of tile kt have landed and its LDS reads of tile kt-1 are done; then everyone's
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + 1 < k1) stage(cur ^ 1, kt + 1);
+        const int cur = (kt - k0) % T::STAGES;
+        // this wave's pieces of tile kt have landed (with 3 stages tile kt+1 may still be in flight) and its LDS
+        // reads of tile kt-1 are done; then everyone's
+        if (T::STAGES == 3 && kt + 1 < k1) {
+            constexpr int PFULL = T::PA + T::PB, PLESS = T::PA - 1 + T::PB;
+            if (T::PA_TOTAL % NWAVES == 0 || extra_a)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PFULL) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(PLESS) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (kt + T::STAGES - 1 < k1) stage((cur + T::STAGES - 1) % T::STAGES, kt + T::STAGES - 1);
         const char* At = smem + cur * T::STAGE_BYTES;
         const char* Wt = At + T::A_BYTES;
 #pragma unroll
@@ -331,7 +349,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_streamk_kernel(GemmArgs g, S
 
 template <int EPI, int BM, int WM, int WN>
 int launch_cfg(const GemmArgs& g, hipStream_t s) {
-    constexpr int LDS = 2 * (BM + BN) * 128;
+    constexpr int LDS = Tile<BM, WM, WN>::LDS_BYTES;
     static bool attr_set = false;
     auto fn = gemm_bt_kernel<EPI, BM, WM, WN>;
     if (!attr_set) {
