@@ -16,7 +16,7 @@ MM_DEVICE void wait_vm_lgkm() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int STAGES, int MINW>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int MINW, bool NOSTORE = false>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var_kernel(GemmArgs g) {
     constexpr int NW = WM * WN;
     constexpr int RB = BK * 2;          // bytes per LDS row
@@ -698,11 +698,11 @@ int launch_big(const GemmArgs& g, hipStream_t s) {
     return 0;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int STAGES, int MINW>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int MINW, bool NOSTORE = false>
 int launch_var(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = STAGES * (BM + BN) * BK * 2;
     static bool attr_set = false;
-    auto fn = gemm_var_kernel<BM, BN, BK, WM, WN, STAGES, MINW>;
+    auto fn = gemm_var_kernel<BM, BN, BK, WM, WN, STAGES, MINW, NOSTORE>;
     if (!attr_set) {
         MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
@@ -731,6 +731,7 @@ int launch_gemm_variant(int variant, const GemmArgs& g, hipStream_t s) {
         case 9: return launch_var<128, 256, 32, 2, 2, 3, 2>(g, s);
         case 10: return launch_var<256, 256, 64, 4, 4, 2, 4>(g, s);
         case 11: return launch_var<256, 256, 32, 4, 4, 4, 4>(g, s);
+        case 40: return launch_var<256, 256, 64, 4, 4, 2, 4, true>(g, s);  // v10 without the epilogue stores
         // 32x32x16 MFMA:    BM   BN  WM WN ST MINW
         case 12: return launch_var32<128, 128, 2, 2, 2, 2>(g, s);
         case 13: return launch_var32<256, 256, 4, 4, 2, 4>(g, s);

@@ -297,14 +297,20 @@ def test_teacher_forced_tiny_trajectory(tiny_model):
 
 
 # ------------------------------------------------------------------------------------------------- tensor parallel
-@pytest.mark.parametrize("tp", [2])
+@pytest.mark.parametrize("tp", [2, 4, 8])
 def test_tensor_parallel_slices_on_one_gpu(tiny_model, tp):
-    """TP=2 emulated on one GPU: two handles (tp_rank 0/1) from the same checkpoint, the all-reduce replaced by an
+    """TP=2/4/8 emulated on one GPU: one handle per tp_rank from the same checkpoint, the all-reduce replaced by an
     explicit sum of their partial residual streams.  Must agree with the TP=1 forward up to bf16 re-association."""
     from mmada_parallel_amd import LLaDAForMultiModalGeneration, abi
 
-    cfg = synth.full_config(synth.CFG_TINY)
-    ranks = [LLaDAForMultiModalGeneration.from_state_dict(cfg, tiny_sd(), device=DEV, tp_rank=r, tp_size=tp)
+    if tp == 2:
+        base, sd_, ref_model = synth.CFG_TINY, tiny_sd(), tiny_model
+    else:  # 8 heads so that every rank owns at least one
+        base = dict(synth.CFG_TINY, d_model=1024, n_heads=8, n_kv_heads=8, mlp_hidden_size=2048)
+        sd_ = synth.synthetic_state_dict(base, seed=5)
+        ref_model = LLaDAForMultiModalGeneration.from_state_dict(synth.full_config(base), sd_, device=DEV)
+    cfg = synth.full_config(base)
+    ranks = [LLaDAForMultiModalGeneration.from_state_dict(cfg, sd_, device=DEV, tp_rank=r, tp_size=tp)
              for r in range(tp)]
     job = tiny_job()
     ids = job["input_ids"].repeat(2, 1).to(DEV)
@@ -327,15 +333,17 @@ def test_tensor_parallel_slices_on_one_gpu(tiny_model, tp):
             for v in views:
                 v.copy_(total)
     got = ranks[0].hidden_state().float().cpu()
-    tiny_model.forward_body(ids)
-    ref = tiny_model.hidden_state().float().cpu()
+    ref_model.forward_body(ids)
+    ref = ref_model.hidden_state().float().cpu()
     err = (got - ref).abs().max().item() / ref.abs().max().item()
     print(f"TP={tp} vs TP=1 hidden rel err {err:.3e}")
     assert err < 2.0 ** -5   # a few bf16 ulps of the stream: the two partial sums are rounded before they are added
     rows = torch.arange(B * L, dtype=torch.int32, device=DEV)
     lg = ranks[0].head_rows(rows, synth.TEXT_VOCAB, synth.TEXT_VOCAB + 512).float().cpu()
-    lr = tiny_model.head_rows(rows, synth.TEXT_VOCAB, synth.TEXT_VOCAB + 512).float().cpu()
+    lr = ref_model.head_rows(rows, synth.TEXT_VOCAB, synth.TEXT_VOCAB + 512).float().cpu()
     assert (lg - lr).abs().max().item() < 2.0 ** -5 * lr.abs().max().item()
+    if tp != 2:
+        ref_model.forward_body(ids[:1])
 
 
 def test_microbatched_overlap_path_matches_single_context(tiny_model, monkeypatch):
