@@ -431,3 +431,28 @@ def test_m_interleave_stub_trajectory_bit_exact(tiny_model, name):
     assert got.shape == ref.shape and torch.equal(got, ref)
     assert torch.equal(img.cpu(), torch.from_numpy(z[name + "_img"]))
     assert torch.equal(text.cpu(), torch.from_numpy(z[name + "_text"]))
+
+
+def test_from_pretrained_reads_reference_checkpoint_layout(tmp_path, tiny_model):
+    """config.json + *.safetensors with the reference's state-dict keys load unchanged."""
+    import json
+
+    from safetensors.torch import save_file
+
+    from mmada_parallel_amd import LLaDAForMultiModalGeneration
+
+    sd = tiny_sd()
+    keys = sorted(sd)
+    half = len(keys) // 2   # two shards, like a sharded HF checkpoint
+    save_file({k: sd[k].contiguous() for k in keys[:half]}, str(tmp_path / "model-00001-of-00002.safetensors"))
+    save_file({k: sd[k].contiguous() for k in keys[half:]}, str(tmp_path / "model-00002-of-00002.safetensors"))
+    cfg = {k: v for k, v in synth.full_config(synth.CFG_TINY).items() if isinstance(v, (int, float, str, bool, type(None)))}
+    with open(tmp_path / "config.json", "w") as f:
+        json.dump(cfg, f)
+    m = LLaDAForMultiModalGeneration.from_pretrained(str(tmp_path), torch_dtype=torch.bfloat16, device_map="auto")
+    assert m.config.d_model == 256 and m.device.type == "cuda"
+    ids = tiny_job()["input_ids"].to(DEV)
+    m.forward_body(ids)
+    tiny_model.forward_body(ids)
+    assert torch.equal(m.hidden_state(), tiny_model.hidden_state())
+    assert getattr(m.config, "text_vocab_size", 126356) == 126356

@@ -1,0 +1,73 @@
+"""Host-side logic (no GPU): schedules, sequence layout, prompt templates — checked against the reference's own
+formulas (generators/parallel_generator.py:73-99,157-159,318-321; inference.py:117-161; SURVEY.md §8d numbers)."""
+import math
+
+import torch
+
+from mmada_parallel_amd import synth
+from mmada_parallel_amd.generators import interleave_generator as ig
+from mmada_parallel_amd.generators import parallel_generator as pg
+from mmada_parallel_amd.utils import (SPECIAL_TOKENS, add_break_line, build_ti2ti_sequence, calculate_vq_params,
+                                      generate_text_image_to_text_image_prompt)
+
+
+def test_num_transfer_tokens_a_variant():
+    for total, steps in [(256, 128), (256, 100), (16, 8), (16, 7), (5, 9), (0, 4)]:
+        m = torch.zeros(1, 300, dtype=torch.bool)
+        m[0, :total] = True
+        got = pg.get_num_transfer_tokens(m, steps)[0].tolist()
+        remaining, want = total, []
+        for s in range(steps):  # reference :88-97
+            t = max(0, remaining - int(total * (1 - (s + 1) / steps)))
+            want.append(t)
+            remaining -= t
+        assert got == want and sum(got) == total
+
+
+def test_num_transfer_tokens_m_variant():
+    m = torch.zeros(2, 64, dtype=torch.bool)
+    m[0, :50] = True
+    m[1, :7] = True
+    got = ig.get_num_transfer_tokens(m, 8)
+    assert got[0].tolist() == [7, 7, 6, 6, 6, 6, 6, 6] and got[1].tolist() == [1] * 7 + [0]
+
+
+def test_image_step_schedule_and_mask_len():
+    assert len(set(pg.image_step_indices(128, 64))) == 64 and min(pg.image_step_indices(128, 64)) == 32
+    assert len(set(pg.image_step_indices(32, 16))) == 16
+    ml = pg.mask_len_schedule(1024, 128)
+    assert ml[-1] == -1  # fp32 cos(pi/2) < 0 -> exactly one token is left for the random fill
+    for s in (0, 17, 63, 126):
+        r = (s + 1) / 128
+        assert ml[s] == int(math.floor(1024 * float(torch.cos(torch.tensor(r) * math.pi / 2))))
+
+
+def test_sequence_layout_matches_survey_numbers():
+    job = synth.synthetic_job(512, 512, text_gen_length=256, prompt_len=64, uncond_prompt_len=24, seed=1)
+    ids = job["input_ids"][0].tolist()
+    assert len(ids) == 2438 and job["image_start"] == 1124 and job["text_start"] == 2181 and job["text_end"] == 2437
+    assert job["seq_len"] == 1024 and job["newline_every"] == 32
+    job1 = synth.synthetic_job(256, 256, text_gen_length=256, prompt_len=64, uncond_prompt_len=24, seed=1)
+    assert job1["input_ids"].shape[1] == 1654 and job1["seq_len"] == 256 and job1["newline_every"] == 16
+
+
+def test_build_ti2ti_sequence():
+    T = SPECIAL_TOKENS
+    prompt, unc = list(range(100, 110)), list(range(200, 205))
+    seq_len, nl_every, gh, gw = calculate_vq_params(64, 64)
+    img = [T["boi"]] + add_break_line([T["image_token_offset"] + i for i in range(seq_len)], gh, gw, T["newline_token"]) + [T["eoi"]]
+    s = build_ti2ti_sequence(prompt, unc, img, 64, 64, text_gen_length=12, end_token_ids=[T["answer_end"]])
+    ids = s["input_ids"]
+    assert ids[:9] == prompt[:-1] and ids[9:9 + len(img)] == img and ids[9 + len(img)] == prompt[-1]
+    assert ids[s["code_start"]] == T["answer_start"] and ids[s["image_start"] - 1] == T["boi"]
+    assert ids[s["image_end"]] == T["eoi"] and s["text_start"] == s["image_end"] + 1
+    span = ids[s["image_start"]:s["image_end"]]
+    assert span.count(T["mask_token"]) == seq_len and span.count(T["newline_token"]) == gh
+    assert ids[s["text_start"]:s["text_end"]] == [T["mask_token"]] * 12 and ids[-1] == T["answer_end"]
+    assert s["uncon_text"] == unc[:-1] + img + unc[-1:] and s["uncon_image"] == prompt
+    assert len(s["uncon_text"]) < s["code_start"]  # the uncond prefix overwrite stays inside the conditioning part
+
+
+def test_prompt_template():
+    a, b = generate_text_image_to_text_image_prompt("make it red", "SYS")
+    assert a == "<system>SYS</system><user>make it red</user>" and b == "<system>SYS</system><user><uncondition></user>"
