@@ -16,7 +16,7 @@ MM_DEVICE void wait_vm_lgkm() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int STAGES, int MINW, bool NOSTORE = false>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int MINW, bool NOSTORE = false, bool NODMA = false, bool NOLDS = false>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var_kernel(GemmArgs g) {
     constexpr int NW = WM * WN;
     constexpr int RB = BK * 2;          // bytes per LDS row
@@ -88,7 +88,8 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var_kernel(GemmArgs g
             wait_vm_lgkm<(STAGES - 2) * (PA + PB)>();
         else
             wait_vm_lgkm<0>();
-        if (kt + STAGES - 1 < nk) stage((kt + STAGES - 1) % STAGES, kt + STAGES - 1);
+        // NODMA probe: only the first tiles are ever fetched (wrong results; isolates the cost of the global->LDS stream)
+        if (kt + STAGES - 1 < nk && (!NODMA || kt < 2)) stage((kt + STAGES - 1) % STAGES, kt + STAGES - 1);
         const char* At = smem + (kt % STAGES) * STAGE_BYTES;
         const char* Wt = At + A_BYTES;
 #pragma unroll
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var_kernel(GemmArgs g
 
 // Same pipeline with v_mfma_f32_32x32x16_bf16 (one ds_read_b128 per 32x16 operand fragment; C layout
 // col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)).
-template <int BM, int BN, int WM, int WN, int STAGES, int MINW>
+template <int BM, int BN, int WM, int WN, int STAGES, int MINW, bool PROBE = false>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var32_kernel(GemmArgs g) {
     constexpr int BK = 64, NW = WM * WN, RB = 128, CPR = 8, RPP = 8;
     constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, STAGE_BYTES = A_BYTES + B_BYTES;
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var32_kernel(GemmArgs
             wait_vm_lgkm<(STAGES - 2) * (PA + PB)>();
         else
             wait_vm_lgkm<0>();
-        if (kt + STAGES - 1 < nk) stage((kt + STAGES - 1) % STAGES, kt + STAGES - 1);
+        if (kt + STAGES - 1 < nk && (!PROBE || kt < 2)) stage((kt + STAGES - 1) % STAGES, kt + STAGES - 1);
         const char* At = smem + (kt % STAGES) * STAGE_BYTES;
         const char* Wt = At + A_BYTES;
 #pragma unroll
@@ -197,12 +198,14 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var32_kernel(GemmArgs
 #pragma unroll
             for (int mi = 0; mi < FM; ++mi) {
                 const int row = wm * TM + mi * 32 + frow;
-                a[mi] = *(const bf16x8*)(At + row * RB + (((ks * 2 + hi) ^ ((row >> 1) & 7)) << 4));
+                if (!PROBE || kt == 0) a[mi] = *(const bf16x8*)(At + row * RB + (((ks * 2 + hi) ^ ((row >> 1) & 7)) << 4));
+                if (PROBE) asm volatile("" : "+v"(a[mi]));
             }
 #pragma unroll
             for (int ni = 0; ni < FN; ++ni) {
                 const int row = wn * TN + ni * 32 + frow;
-                b[ni] = *(const bf16x8*)(Wt + row * RB + (((ks * 2 + hi) ^ ((row >> 1) & 7)) << 4));
+                if (!PROBE || kt == 0) b[ni] = *(const bf16x8*)(Wt + row * RB + (((ks * 2 + hi) ^ ((row >> 1) & 7)) << 4));
+                if (PROBE) asm volatile("" : "+v"(b[ni]));
             }
 #pragma unroll
             for (int mi = 0; mi < FM; ++mi)
@@ -225,11 +228,11 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var32_kernel(GemmArgs
         }
 }
 
-template <int BM, int BN, int WM, int WN, int STAGES, int MINW>
+template <int BM, int BN, int WM, int WN, int STAGES, int MINW, bool PROBE = false>
 int launch_var32(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = STAGES * (BM + BN) * 128;
     static bool attr_set = false;
-    auto fn = gemm_var32_kernel<BM, BN, WM, WN, STAGES, MINW>;
+    auto fn = gemm_var32_kernel<BM, BN, WM, WN, STAGES, MINW, PROBE>;
     if (!attr_set) {
         MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
@@ -653,6 +656,125 @@ __global__ __launch_bounds__(512, 2) void gemm_pp2_kernel(GemmArgs g) {
         }
 }
 
+// 32x32x16 MFMA, 8 waves (2 x 4) of 128x64, register double-buffered fragments: the 6 ds_read_b128 of k-step s+1
+// are issued before the 8 MFMAs of k-step s (software pipelining inside the wave), one barrier per K-tile.
+template <int WAVES_M, int WAVES_N, int MINW>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, MINW) void gemm_swp32_kernel(GemmArgs g) {
+    constexpr int BM = 256, BN = 256, BK = 64, NW = WAVES_M * WAVES_N, A_BYTES = BM * 128, STAGE_BYTES = (BM + BN) * 128;
+    constexpr int TM = BM / WAVES_M, TN = BN / WAVES_N, FM = TM / 32, FN = TN / 32;
+    constexpr int PA = BM / 8 / NW, PB = BN / 8 / NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    constexpr int GN = 4;
+    const int gsize = GN * ntm;
+    const int grp_t = id / gsize, rem = id - grp_t * gsize;
+    const int gn = min(GN, ntn - grp_t * GN);
+    const int mt = rem / gn, nt = grp_t * GN + (rem - (rem / gn) * gn);
+    const int m0 = mt * BM, n0 = nt * BN;
+    const bf16_t* asrc[PA];
+    const bf16_t* wsrc[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int row = (wave * PA + i) * 8 + (lane >> 3);
+        asrc[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int row = (wave * PB + i) * 8 + (lane >> 3);
+        wsrc[i] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw + ((lane & 7) ^ ((row >> 1) & 7)) * 8;
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BK), (lptr_t)(base + (wave * PA + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kt * BK), (lptr_t)(base + A_BYTES + (wave * PB + i) * 1024),
+                                             16, 0, 0);
+    };
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int frow = lane & 31, hi = lane >> 5;
+    int aoff[FM], boff[FN];  // row*128 of this lane's fragment rows; chunk term added per k-step
+    int asw[FM], bsw[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) { const int row = wm * TM + i * 32 + frow; aoff[i] = row * 128; asw[i] = (row >> 1) & 7; }
+#pragma unroll
+    for (int i = 0; i < FN; ++i) { const int row = wn * TN + i * 32 + frow; boff[i] = A_BYTES + row * 128; bsw[i] = (row >> 1) & 7; }
+    bf16x8 fa[2][FM], fb[2][FN];
+    auto rd = [&](const char* st, int ks, bf16x8 (&a)[FM], bf16x8 (&b)[FN]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i) a[i] = *(const bf16x8*)(st + aoff[i] + (((ks * 2 + hi) ^ asw[i]) << 4));
+#pragma unroll
+        for (int i = 0; i < FN; ++i) b[i] = *(const bf16x8*)(st + boff[i] + (((ks * 2 + hi) ^ bsw[i]) << 4));
+    };
+    auto mma = [&](bf16x8 (&a)[FM], bf16x8 (&b)[FN]) {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    };
+    const int nk = g.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const char* st = smem + (kt & 1) * STAGE_BYTES;
+        rd(st, 0, fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(st, 1, fa[1], fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(st, 2, fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa[1], fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        rd(st, 3, fa[1], fb[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa[1], fb[1]);
+    }
+#pragma unroll
+    for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * TM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < FN; ++ni) {
+                const int n = n0 + wn * TN + ni * 32 + frow;
+                if (n < g.N) g.C[(size_t)m * g.ldc + n] = f2bf(acc[mi][ni][r]);
+            }
+        }
+}
+
+template <int WAVES_M, int WAVES_N, int MINW>
+int launch_swp32(const GemmArgs& g, hipStream_t s) {
+    constexpr int LDS = 2 * 512 * 128;
+    static bool attr_set = false;
+    auto fn = gemm_swp32_kernel<WAVES_M, WAVES_N, MINW>;
+    if (!attr_set) {
+        MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int ntm = (g.M + 255) / 256, ntn = (g.N + 255) / 256;
+    hipLaunchKernelGGL(fn, dim3(ntm * ntn), dim3(64 * WAVES_M * WAVES_N), LDS, s, g);
+    MM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 template <int NPH>
 int launch_pp2(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = 2 * 512 * 128;
@@ -698,11 +820,11 @@ int launch_big(const GemmArgs& g, hipStream_t s) {
     return 0;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int STAGES, int MINW, bool NOSTORE = false>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int MINW, bool NOSTORE = false, bool NODMA = false, bool NOLDS = false>
 int launch_var(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = STAGES * (BM + BN) * BK * 2;
     static bool attr_set = false;
-    auto fn = gemm_var_kernel<BM, BN, BK, WM, WN, STAGES, MINW, NOSTORE>;
+    auto fn = gemm_var_kernel<BM, BN, BK, WM, WN, STAGES, MINW, NOSTORE, NODMA, NOLDS>;
     if (!attr_set) {
         MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
@@ -732,9 +854,13 @@ int launch_gemm_variant(int variant, const GemmArgs& g, hipStream_t s) {
         case 10: return launch_var<256, 256, 64, 4, 4, 2, 4>(g, s);
         case 11: return launch_var<256, 256, 32, 4, 4, 4, 4>(g, s);
         case 40: return launch_var<256, 256, 64, 4, 4, 2, 4, true>(g, s);  // v10 without the epilogue stores
+        case 41: return launch_var<256, 256, 64, 4, 4, 2, 4, false, true>(g, s);  // v10 without the global->LDS stream
+        case 42: return launch_var<256, 256, 64, 4, 4, 2, 4, false, true, true>(g, s);  // ... and without LDS reads
         // 32x32x16 MFMA:    BM   BN  WM WN ST MINW
         case 12: return launch_var32<128, 128, 2, 2, 2, 2>(g, s);
         case 13: return launch_var32<256, 256, 4, 4, 2, 4>(g, s);
+        case 43: return launch_var32<256, 256, 4, 4, 2, 4, true>(g, s);  // 32x32x16 MFMA-only probe
+        case 44: return launch_var32<256, 256, 2, 4, 2, 2, true>(g, s);  // same, 8 waves of 128x64
         case 14: return launch_var32<256, 256, 2, 4, 2, 2>(g, s);
         case 15: return launch_var32<256, 128, 4, 2, 2, 2>(g, s);
         case 16: return launch_var32<256, 128, 4, 4, 3, 4>(g, s);
@@ -742,6 +868,8 @@ int launch_gemm_variant(int variant, const GemmArgs& g, hipStream_t s) {
         case 18: return launch_var<256, 256, 64, 4, 2, 2, 2>(g, s);
         case 30: return launch_pp<false, 0>(g, s);
         case 31: return launch_pp<true, 0>(g, s);
+        case 50: return launch_swp32<2, 4, 2>(g, s);
+        case 51: return launch_swp32<4, 4, 4>(g, s);
         case 34: return launch_pp2<4>(g, s);
         case 35: return launch_pp2<2>(g, s);
         case 32: return launch_pp<false, 1>(g, s);
