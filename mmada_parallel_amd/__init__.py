@@ -4,7 +4,7 @@ Public surface mirrors the reference (tyfeld/MMaDA-Parallel, MMaDA-Parallel-A):
     from mmada_parallel_amd import LLaDAForMultiModalGeneration, generate_ti2ti
 """
 from .model import LLaDAForMultiModalGeneration, LLaDAConfigLite  # noqa: F401
-from .generators.parallel_generator import generate_ti2ti, cosine_schedule  # noqa: F401
+from .generators.parallel_generator import generate_ti2ti, generate_ti2ti_stepwise, cosine_schedule  # noqa: F401
 from .generators.interleave_generator import interleave_generate  # noqa: F401
 
-__all__ = ["LLaDAForMultiModalGeneration", "LLaDAConfigLite", "generate_ti2ti", "interleave_generate", "cosine_schedule"]
+__all__ = ["LLaDAForMultiModalGeneration", "LLaDAConfigLite", "generate_ti2ti", "generate_ti2ti_stepwise", "interleave_generate", "cosine_schedule"]

@@ -75,8 +75,7 @@ def add_gumbel_noise(logits, temperature=1.0, generator=None):
     return logits + temperature * g
 
 
-@torch.no_grad()
-def generate_ti2ti(
+def _ti2ti_steps(
     model,
     input_ids,
     text_start,
@@ -100,12 +99,11 @@ def generate_ti2ti(
     generator=None,
     text_vocab_size=126356,
     codebook_size=8192,
-    return_state=False,
+    image_step_list=None,
 ):
-    """Joint text+image generation; returns (List[int] vq ids, str | List[int] text) like the reference.
-
-    `return_state=True` additionally returns the final `combined_input_ids` *before* the random fill of
-    still-masked image tokens (reference :360-362) — the quantity parity tests compare (SURVEY A.1)."""
+    """Generator core shared by generate_ti2ti and generate_ti2ti_stepwise: runs the reference loop and yields
+    (step, ids, info) after every step; `info` carries the image step's sampled ids (before re-masking) when one ran.
+    `image_step_list` overrides the schedule of image steps (default: reference :157-159)."""
     if not isinstance(model, LLaDAForMultiModalGeneration):
         raise TypeError("generate_ti2ti (MI355X) needs mmada_parallel_amd.LLaDAForMultiModalGeneration; "
                         "there is no PyTorch fallback path")
@@ -127,7 +125,7 @@ def generate_ti2ti(
     text_masked0 = ids_host[:, text_start:text_end] == MASK_TOKEN
     num_transfer = get_num_transfer_tokens(text_masked0, text_steps)  # [B, steps]
     remaining_text = text_masked0.sum(dim=1)  # [B]
-    img_steps = set(image_step_indices(text_steps, timesteps))
+    img_steps = set(image_step_indices(text_steps, timesteps) if image_step_list is None else image_step_list)
     pos_list = [i for i in range(image_start, image_end) if ids_host[0, i] != NEW_LINE]
     assert len(pos_list) == num_vq_tokens, f"Expected {num_vq_tokens} VQ tokens, got {len(pos_list)}"
     mlen = mask_len_schedule(num_vq_tokens, text_steps, noise_schedule)
@@ -173,6 +171,7 @@ def generate_ti2ti(
                       "mmada_text_select")
             masked_left = masked_left - num_transfer[:, step]
 
+        info = {"image_step": is_img, "sampled": None}
         # ===== image step (reference :220-344) =====
         if is_img:
             ut = ui = None
@@ -215,6 +214,49 @@ def generate_ti2ti(
                                              p_sel.data_ptr(), noise.data_ptr(), float(img_temp),
                                              mlen_dev[step:step + 1].data_ptr(), int(text_vocab_size),
                                              int(codebook_size), st), "mmada_image_commit")
+            info["sampled"] = sampled
+        yield step, ids, info
+    yield text_steps, ids, {"image_step": False, "sampled": None, "pos_list": pos_list}
+
+
+@torch.no_grad()
+def generate_ti2ti(
+    model,
+    input_ids,
+    text_start,
+    text_end,
+    image_start,
+    seq_len,
+    newline_every,
+    text_steps=100,
+    text_gen_length=256,
+    text_block_length=64,
+    timesteps=100,
+    temperature=1.0,
+    text_temperature=0.7,
+    cfg_scale=0.0,
+    cfg_img=4.0,
+    uncon_text=None,
+    uncon_image=None,
+    tokenizer=None,
+    remasking='low_confidence',
+    noise_schedule=cosine_schedule,
+    generator=None,
+    text_vocab_size=126356,
+    codebook_size=8192,
+    return_state=False,
+):
+    """Joint text+image generation; returns (List[int] vq ids, str | List[int] text) like the reference
+    (generators/parallel_generator.py:102-368).
+
+    `return_state=True` additionally returns the final `combined_input_ids` *before* the random fill of
+    still-masked image tokens (reference :360-362) — the quantity parity tests compare (SURVEY A.1)."""
+    ids = pos_list = None
+    for _step, ids, info in _ti2ti_steps(model, input_ids, text_start, text_end, image_start, seq_len, newline_every,
+                                         text_steps, text_gen_length, text_block_length, timesteps, temperature,
+                                         text_temperature, cfg_scale, cfg_img, uncon_text, uncon_image, tokenizer,
+                                         remasking, noise_schedule, generator, text_vocab_size, codebook_size):
+        pos_list = info.get("pos_list", pos_list)
 
     # ===== final read-out (reference :346-368) =====
     final_ids = ids.cpu()
@@ -231,3 +273,35 @@ def generate_ti2ti(
     if return_state:
         return image_tokens, generated_text, final_ids
     return image_tokens, generated_text
+
+
+def stepwise_image_steps(text_steps: int):
+    """Image-step schedule of the reference's Gradio generator (app.py:162-164): 30 % of the steps, from step 0."""
+    return torch.linspace(0, text_steps - 1, int(text_steps * 0.3)).round().int().tolist()
+
+
+def generate_ti2ti_stepwise(
+    model, input_ids, text_start, text_end, image_start, seq_len, newline_every,
+    text_steps=100, temperature=1.0, text_temperature=0.7, cfg_scale=0.0, cfg_img=4.0,
+    uncon_text=None, uncon_image=None, tokenizer=None, remasking='low_confidence',
+    noise_schedule=cosine_schedule, generator=None, text_vocab_size=126356,
+    codebook_size=8192, vqvae=None, image_height=512, image_width=512,
+):
+    """Token-level mirror of the reference's streaming sampler `generate_ti2ti_stepwise` (app.py:143-398): the same
+    loop as generate_ti2ti with the Gradio schedule of image steps, yielding after every step
+
+        (step + 1, combined_input_ids [B, L] on the device, sampled VQ ids [B, N] of this step's image update or None,
+         show)   with show == the reference's display cadence (step % 5 == 0, image steps, last step).
+
+    Decoding the ids to text / pixels (tokenizer, VQ-VAE: `vqvae`, `image_height`, `image_width`) is the caller's UI
+    work and is not done here (the VQ-VAE is third-party `diffusers` code)."""
+    sched = stepwise_image_steps(text_steps)
+    with torch.no_grad():
+        for step, ids, info in _ti2ti_steps(model, input_ids, text_start, text_end, image_start, seq_len, newline_every,
+                                            text_steps, 256, 64, 0, temperature, text_temperature, cfg_scale, cfg_img,
+                                            uncon_text, uncon_image, tokenizer, remasking, noise_schedule, generator,
+                                            text_vocab_size, codebook_size, image_step_list=sched):
+            if step >= text_steps:
+                return
+            show = step % 5 == 0 or info["image_step"] or step == text_steps - 1
+            yield step + 1, ids, info["sampled"], show

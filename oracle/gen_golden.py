@@ -253,6 +253,53 @@ def gen_m_traj():
             sys.modules[k] = v
 
 
+def gen_stepwise_traj():
+    """Reference Gradio sampler generate_ti2ti_stepwise (app.py:143-398) on stub logits; gradio / diffusers are
+    absent here and only used for UI / VQ decode, so they are stubbed (the decode call sits in a try/except)."""
+    import importlib
+    import types
+
+    from unittest import mock
+
+    for name in ("gradio", "diffusers", "diffusers.image_processor"):
+        if name not in sys.modules:
+            sys.modules[name] = mock.MagicMock()  # app.py builds its gr.Blocks UI at import time
+    app = importlib.import_module("app")
+
+    class Tok:
+        def decode(self, ids, **_):
+            return "x"
+
+    job = tiny_job()
+    V = STUB_TEXT_VOCAB + STUB_CB
+    out = {}
+    for ci, (name, kw) in enumerate({"sw_img4": dict(text_steps=10, cfg_scale=0.0, cfg_img=4.0),
+                                     "sw_both": dict(text_steps=14, cfg_scale=2.5, cfg_img=4.0)}.items()):
+        seed = 51 + ci
+
+        def fn(ids, call_idx, seed=seed):
+            return SimpleNamespace(logits=stub_logits(seed, call_idx, ids.shape[0], ids.shape[1], V))
+
+        rec = Recorder(fn)
+        torch.manual_seed(4321)
+        steps = []
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            try:
+                for s_ in app.generate_ti2ti_stepwise(
+                        rec, job["input_ids"], job["text_start"], job["text_end"], job["image_start"], job["seq_len"],
+                        job["newline_every"], temperature=0.0, text_temperature=0.0, uncon_text=job["uncon_text"],
+                        uncon_image=job["uncon_image"], tokenizer=Tok(), text_vocab_size=STUB_TEXT_VOCAB,
+                        codebook_size=STUB_CB, vqvae=None, image_height=64, image_width=64, **kw):
+                    steps.append(s_[0])
+            except Exception:
+                pass  # the final VQ-VAE decode (mocked diffusers) fails after the sampling loop has finished
+        out[name + "_calls"] = torch.cat(rec.calls, 0).numpy()
+        out[name + "_yields"] = np.array(steps)
+        out[name + "_seed"] = np.array(seed)
+        print(f"stepwise_traj[{name}]: {len(rec.calls)} model calls, yields at {steps}")
+    np.savez_compressed(os.path.join(OUT, "stepwise_traj.npz"), **out)
+
+
 def gen_tables():
     b = torch.arange(0, 0x7f80, dtype=torch.int32).to(torch.int16)
     np.save(os.path.join(OUT, "logconf_table.npy"), torch.log(b.view(torch.bfloat16) + 1e-10).view(torch.int16).numpy())
@@ -263,6 +310,7 @@ if __name__ == "__main__":
         sys.exit("reference not mounted at " + REF)
     os.makedirs(OUT, exist_ok=True)
     gen_tables()
+    gen_stepwise_traj()
     gen_m_traj()
     gen_sampler_traj()
     gen_forward()

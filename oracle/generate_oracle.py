@@ -32,7 +32,8 @@ def get_num_transfer_tokens(n_masked: int, steps: int) -> List[int]:
 def generate(model_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.Tensor, text_start: int, text_end: int,
              image_start: int, seq_len: int, newline_every: int, text_steps: int, timesteps: int,
              cfg_scale: float, cfg_img: float, uncon_text: Optional[torch.Tensor], uncon_image: Optional[torch.Tensor],
-             text_vocab_size: int = 126356, codebook_size: int = 8192, trace: Optional[list] = None) -> torch.Tensor:
+             text_vocab_size: int = 126356, codebook_size: int = 8192, trace: Optional[list] = None,
+             image_step_list: Optional[list] = None) -> torch.Tensor:
     """temperature = text_temperature = 0 path.  Returns the final ids before the random fill (:360-362)."""
     ids = input_ids.clone()
     assert ids.shape[0] == 1
@@ -40,6 +41,8 @@ def generate(model_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.
     n_text_masked = int((ids[0, text_start:text_end] == MASK_TOKEN).sum())
     k_sched = get_num_transfer_tokens(n_text_masked, text_steps)
     img_steps = torch.linspace(text_steps // 4, text_steps - 1, timesteps).round().int().tolist()  # :157-159
+    if image_step_list is not None:  # app.py:162-164 (Gradio sampler): linspace(0, text_steps-1, int(0.3*text_steps))
+        img_steps = list(image_step_list)
     pos = [i for i in range(image_start, image_end) if int(ids[0, i]) != NEW_LINE]  # :164-169
     assert len(pos) == seq_len
     lo, hi = text_vocab_size, text_vocab_size + codebook_size

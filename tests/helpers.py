@@ -53,3 +53,5 @@ M_CASES = {
     "m_noisy": dict(text_cfg=0.7, image_cfg=3.5, text_steps=6, image_steps=3, image_temperature=1.0, text_temperature=0.8),
 }
 M_SHAPE = dict(prompt=6, N=16, T=16, text_vocab=2048, CB=512, soi=2040, eoi=2041, bos=2042, mask_id=126336)
+
+STEPWISE_CASES = {"sw_img4": dict(text_steps=10, cfg_scale=0.0, cfg_img=4.0), "sw_both": dict(text_steps=14, cfg_scale=2.5, cfg_img=4.0)}

@@ -456,3 +456,29 @@ def test_from_pretrained_reads_reference_checkpoint_layout(tmp_path, tiny_model)
     tiny_model.forward_body(ids)
     assert torch.equal(m.hidden_state(), tiny_model.hidden_state())
     assert getattr(m.config, "text_vocab_size", 126356) == 126356
+
+
+# ----------------------------------------------------------------- Gradio sampler (app.py:143-398), token level
+from helpers import STEPWISE_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(STEPWISE_CASES))
+def test_stepwise_generator_bit_exact(tiny_model, name):
+    from mmada_parallel_amd import generate_ti2ti_stepwise
+
+    z = np.load(os.path.join(GOLDEN, "stepwise_traj.npz"))
+    job, kw = tiny_job(), STEPWISE_CASES[name]
+    V = STUB_TEXT_VOCAB + STUB_CB
+    stub = _stubbed(tiny_model, int(z[name + "_seed"]), V)
+    shown = [0]
+    for step, ids, sampled, show in generate_ti2ti_stepwise(
+            stub, job["input_ids"].to(DEV), job["text_start"], job["text_end"], job["image_start"], job["seq_len"],
+            job["newline_every"], temperature=0.0, text_temperature=0.0, uncon_text=job["uncon_text"],
+            uncon_image=job["uncon_image"], text_vocab_size=STUB_TEXT_VOCAB, codebook_size=STUB_CB, **kw):
+        assert ids.shape == job["input_ids"].shape
+        if show:
+            shown.append(step)
+        if sampled is not None:
+            assert sampled.shape == (1, job["seq_len"]) and int(sampled.min()) >= 0 and int(sampled.max()) < STUB_CB
+    assert torch.equal(torch.cat(stub.calls, 0), torch.from_numpy(z[name + "_calls"]))
+    assert shown == z[name + "_yields"].tolist()   # the reference's display cadence

@@ -179,3 +179,28 @@ def test_m_interleave_trajectory_matches_reference(name):
     assert torch.equal(got, ref), f"first differing forward: {(got != ref).flatten(1).any(1).nonzero()[0].item()}"
     assert torch.equal(img, torch.from_numpy(z[name + "_img"]))
     assert torch.equal(text, torch.from_numpy(z[name + "_text"]))
+
+
+# ---- Gradio sampler generate_ti2ti_stepwise (app.py:143-398): same loop, image steps linspace(0, S-1, int(0.3 S)) ------
+from helpers import STEPWISE_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(STEPWISE_CASES))
+def test_stepwise_trajectory_matches_reference(name):
+    z = np.load(os.path.join(GOLDEN, "stepwise_traj.npz"))
+    seed, job, kw = int(z[name + "_seed"]), tiny_job(), STEPWISE_CASES[name]
+    V = STUB_TEXT_VOCAB + STUB_CB
+    n = [0]
+
+    def model_fn(ids):
+        n[0] += 1
+        return stub_logits(seed, n[0], ids.shape[0], ids.shape[1], V)
+
+    S = kw["text_steps"]
+    sched = torch.linspace(0, S - 1, int(S * 0.3)).round().int().tolist()
+    trace = []
+    generate_oracle.generate(model_fn, job["input_ids"], job["text_start"], job["text_end"], job["image_start"],
+                             job["seq_len"], job["newline_every"], text_steps=S, timesteps=0, cfg_scale=kw["cfg_scale"],
+                             cfg_img=kw["cfg_img"], uncon_text=job["uncon_text"], uncon_image=job["uncon_image"],
+                             text_vocab_size=STUB_TEXT_VOCAB, codebook_size=STUB_CB, trace=trace, image_step_list=sched)
+    assert torch.equal(torch.cat(trace, 0), torch.from_numpy(z[name + "_calls"]))
