@@ -95,6 +95,7 @@ def forward_hidden(sd: Dict[str, torch.Tensor], cfg: dict, input_ids: torch.Tens
     x = F.embedding(input_ids, sd["model.transformer.wte.weight"])  # :1265
     L = input_ids.shape[1]
     sin, cos = rope_tables(L, cfg["d_model"] // n_heads, cfg.get("rope_theta", 10000.0))
+    sin, cos = sin.to(x.device), cos.to(x.device)
     for i in range(cfg["n_layers"]):
         x = block_forward(x, layer_weights(sd, i), n_heads, n_kv, eps, sin, cos)
         if taps is not None:
