@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--m", default="2438,4876")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--check", action="store_true")
+    ap.add_argument("--fill", default="randn", choices=["randn", "zeros", "ones"],
+                    help="operand data: power (hence clock) depends on it — never quote a zero-fill number")
     ap.add_argument("--cold", type=int, default=6, help="rotate over this many operand copies (defeats the 256 MB MALL)")
     args = ap.parse_args()
     lib = abi.lib()
@@ -33,6 +35,9 @@ def main():
         for name, (N, K) in SHAPES.items():
             A = torch.randn(M, K, device=dev).to(torch.bfloat16)
             W = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
+            if args.fill != "randn":
+                A.fill_(0.0 if args.fill == "zeros" else 1.0)
+                W.fill_(0.0 if args.fill == "zeros" else 1.0)
             C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
             As = [A] + [A.clone() for _ in range(args.cold - 1)]
             Ws = [W] + [W.clone() for _ in range(args.cold - 1)]
