@@ -108,8 +108,9 @@ int mmada_forward(mmada_handle* h, const int64_t* ids, int B, int L, void* logit
 /* Segment entry points for tensor parallelism (the caller interleaves the RCCL all-reduce of the partial
  * buffer returned by mmada_partial_ptr between them):
  *   mmada_embed → for each layer { mmada_attn_partial, [all-reduce], mmada_mlp_partial, [all-reduce] }.
- * *_partial writes  (rank==0 ? x : 0) + local partial of the row-parallel GEMM  into the partial buffer and makes
- * it the new residual stream; summing it over ranks yields the reference's x + attn_out(...) / x + ff_out(...). */
+ * *_partial writes  (own(m) ? x[m] : 0) + local partial of the row-parallel GEMM  into the partial buffer and makes
+ * it the new residual stream, where row m's residual is owned by rank (m >> 4) % tp_size (each rank reads 1/tp of
+ * the old stream); summing it over ranks yields the reference's x + attn_out(...) / x + ff_out(...). */
 int mmada_embed(mmada_handle* h, const int64_t* ids, int B, int L, void* stream);
 int mmada_attn_partial(mmada_handle* h, int layer, void* stream);
 int mmada_mlp_partial(mmada_handle* h, int layer, void* stream);

@@ -296,7 +296,7 @@ int mmada_attn_partial(mmada_handle* h, int layer, void* stream) {
     o.A = h->att; o.W = lw.wo; o.C = h->y;
     o.M = h->M; o.N = d; o.K = h->hq_l * 128;
     o.lda = o.K; o.ldw = o.K; o.ldc = d;
-    o.resid = h->x; o.ldr = d; o.add_resid = (h->cfg.tp_rank == 0);
+    o.resid = h->x; o.ldr = d; o.resid_mod = h->cfg.tp_size; o.resid_rank = h->cfg.tp_rank;
     {
         ProfScope p(h, layer, 2, 2.0 * rows * o.N * o.K, s);
         if (launch_gemm(EPI_RESID, o, s)) return 1;
@@ -325,7 +325,7 @@ int mmada_mlp_partial(mmada_handle* h, int layer, void* stream) {
     o.A = h->hbuf; o.W = lw.wdown; o.C = h->y;
     o.M = h->M; o.N = d; o.K = h->f_l;
     o.lda = h->f_l; o.ldw = h->f_l; o.ldc = d;
-    o.resid = h->x; o.ldr = d; o.add_resid = (h->cfg.tp_rank == 0);
+    o.resid = h->x; o.ldr = d; o.resid_mod = h->cfg.tp_size; o.resid_rank = h->cfg.tp_rank;
     {
         ProfScope p(h, layer, 4, 2.0 * rows * o.N * o.K, s);
         if (launch_gemm(EPI_RESID, o, s)) return 1;

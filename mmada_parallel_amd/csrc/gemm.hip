@@ -172,6 +172,8 @@ MM_DEVICE void epilogue(const GemmArgs& g, int m0, int n0,
             for (int r = 0; r < 4; ++r) {
                 const int m = mrow0 + mi * 16 + r;
                 if (m >= g.M) continue;
+                // wave-uniform: the 16 rows of a fragment share one residual owner
+                const bool add = EPI == EPI_RESID && (g.resid_mod == 1 || ((m >> 4) % g.resid_mod) == g.resid_rank);
 #pragma unroll
                 for (int ni = 0; ni < FN; ++ni) {
                     const int n = wcol0 + ni * 16 + frow;
@@ -179,7 +181,7 @@ MM_DEVICE void epilogue(const GemmArgs& g, int m0, int n0,
                     float v = acc[mi][ni][r];
                     if constexpr (EPI == EPI_RESID) {
                         v = bfround(v);
-                        if (g.add_resid) v = bf2f(g.resid[(size_t)m * g.ldr + n]) + v;
+                        if (add) v = bf2f(g.resid[(size_t)m * g.ldr + n]) + v;
                     }
                     g.C[(size_t)m * g.ldc + n] = f2bf(v);
                 }
@@ -362,24 +364,29 @@ int launch_cfg(const GemmArgs& g, hipStream_t s) {
     return 0;
 }
 
-// Row-tile height: one workgroup per CU, so a launch costs ceil(tiles / 256) row-waves of BM rows each.
-// 2x8 wave grids (BM = 160, 224) move ~25 % more LDS bytes per MFMA than 4x4: small handicap.
-int pick_bm(int M, int N) {
+// Row-tile height.  One workgroup per CU, so a launch runs ceil(tiles / 256) rounds; a round of BM-row tiles costs
+//   t(BM) = A * BM * (K/64) * h(BM)  +  C0 + C1 * BM      [us]
+// (MFMA main loop, with the per-row efficiency h of the wave grid: fewer rows per wave = more LDS bytes per MFMA;
+// plus pipeline fill and the BM x 256 output tile's HBM traffic, which nothing overlaps at one workgroup per CU).
+// Constants are a least-squares fit (rms 6 %) to tools/bm_sweep.sh on MI355X: 240 (shape, M, BM) timings over
+// K = 512..6144, N = 768..6144, M = 2440..19520; choosing by it is within 0.3 % of the best BM on that set.
+int pick_bm(int M, int N, int K) {
     static const int forced = [] {  // MMADA_GEMM_BM=<128|160|192|224|256>: tests / sweeps force one configuration
         const char* e = getenv("MMADA_GEMM_BM");
         return e ? atoi(e) : 0;
     }();
     if (forced == 128 || forced == 160 || forced == 192 || forced == 224 || forced == 256) return forced;
     if (M == 0 && N == 0) return 0;  // query: "is a row-tile height forced?" (no)
-    const int cand[5] = {256, 192, 128, 160, 224};
-    const float handicap[5] = {1.0f, 1.0f, 1.04f, 1.08f, 1.08f};
-    const int ntn = (N + BN - 1) / BN;
+    const int cand[5] = {256, 224, 192, 160, 128};
+    const float h[5] = {1.0f, 1.096f, 1.125f, 1.277f, 1.236f};
+    const float A = 0.00549f, C0 = 2.665f, C1 = 0.03107f;
+    const int ntn = (N + BN - 1) / BN, nk = K / BK;
     int best = 256;
     float best_cost = 1e30f;
     for (int i = 0; i < 5; ++i) {
         const int bm = cand[i];
         const int tiles = ((M + bm - 1) / bm) * ntn;
-        const float cost = (float)((tiles + 255) / 256) * bm * handicap[i];
+        const float cost = (float)((tiles + 255) / 256) * (A * bm * nk * h[i] + C0 + C1 * bm);
         if (cost < best_cost) { best_cost = cost; best = bm; }
     }
     return best;
@@ -454,13 +461,13 @@ template <int EPI>
 int launch_t(const GemmArgs& g, hipStream_t s) {
     // stream-K when the 256x256 tile grid does not fill whole waves of CUs and there is enough K work to share
     const int ntiles = ((g.M + 255) / 256) * ((g.N + BN - 1) / BN), nk = g.K / BK;
-    if (streamk_enabled() && pick_bm(0, 0) == 0) {
+    if (streamk_enabled() && pick_bm(0, 0, 0) == 0) {
         StreamKScratch* w;
         if (streamk_scratch(&w)) return 1;
         if (ntiles % w->grid != 0 && ntiles < 8 * w->grid && (long long)ntiles * nk >= 4LL * w->grid)
             return launch_streamk<EPI>(g, s);
     }
-    switch (pick_bm(g.M, g.N)) {
+    switch (pick_bm(g.M, g.N, g.K)) {
         case 256: return launch_cfg<EPI, 256, 4, 4>(g, s);
         case 192: return launch_cfg<EPI, 192, 4, 4>(g, s);
         case 128: return launch_cfg<EPI, 128, 4, 4>(g, s);

@@ -840,6 +840,7 @@ int launch_var(const GemmArgs& g, hipStream_t s) {
 int launch_gemm_variant(int variant, const GemmArgs& g, hipStream_t s) {
     if (g.K % 64) return mm_fail("gemm_variant: K must be a multiple of 64");
     switch (variant) {
+        case 100: return launch_gemm(EPI_STORE, g, s);  // the production kernel (BM picker included)
         //                 BM   BN  BK WM WN ST MINW
         case 0: return launch_var<128, 128, 64, 2, 2, 2, 2>(g, s);
         case 1: return launch_var<128, 128, 32, 2, 2, 4, 2>(g, s);

@@ -12,10 +12,12 @@ struct GemmArgs {
     bf16_t* C;         // [M, ldc]   (EPI_STORE / EPI_RESID / EPI_SWIGLU: ldc = N/2)
     int M, N, K;
     int lda, ldw, ldc;
-    // EPI_RESID: C = bf16(resid + bf16(acc)) when add_resid, else bf16(acc)
+    // EPI_RESID: C = bf16(resid + bf16(acc)) on the rows this rank owns the residual of, else bf16(acc).
+    // Row m's residual is added by rank (m >> 4) % resid_mod, so that under tensor parallelism every rank reads
+    // 1/tp of the residual stream instead of rank 0 reading all of it (resid_mod = 1: always add).
     const bf16_t* resid;
     int ldr;
-    int add_resid;
+    int resid_mod, resid_rank;
     // EPI_QKV: rows are (b, l) with m = b*Lp + l; columns are [q heads | k heads | v heads] x 128
     bf16_t* q;         // [B, Hq , Lkv, 128]
     bf16_t* k;         // [B, Hkv, Lkv, 128]

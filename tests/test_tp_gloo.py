@@ -15,8 +15,9 @@ from mmada_parallel_amd import synth, tp
 
 
 def _partial_block(x, w, cfg, rank, size, sin, cos):
-    """What one rank computes for a block: (rank==0 ? x : 0) + local partial, for attention then MLP, with the
-    all-reduce in between (same sequence as mmada_attn_partial / all_reduce / mmada_mlp_partial)."""
+    """What one rank computes for a block: (x on the rows this rank owns the residual of, else 0) + local partial,
+    for attention then MLP, with the all-reduce in between (same sequence as mmada_attn_partial / all_reduce /
+    mmada_mlp_partial; row m's residual belongs to rank (m >> 4) % size, kernels.h GemmArgs)."""
     from oracle import llada_oracle as lo
 
     B, T, D = x.shape
@@ -32,12 +33,13 @@ def _partial_block(x, w, cfg, rank, size, sin, cos):
     q, k = lo.apply_rope(q, sin, cos), lo.apply_rope(k, sin, cos)
     att = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).contiguous().view(B, T, hq * hd)
     part = F.linear(att, ws["attn_out"])
-    y = (x + part) if rank == 0 else part
+    own = (((torch.arange(B * T) >> 4) % size) == rank).view(B, T, 1)
+    y = torch.where(own, x + part, part)
     dist.all_reduce(y)
     h = lo.rms_norm(y, ws["ff_norm"], eps)
     hm = F.silu(F.linear(h, ws["ff_proj"])) * F.linear(h, ws["up_proj"])
     part = F.linear(hm, ws["ff_out"])
-    z = (y + part) if rank == 0 else part
+    z = torch.where(own, y + part, part)
     dist.all_reduce(z)
     return z
 

@@ -21,18 +21,22 @@ def main():
     ap.add_argument("--variants", default="0,1,2,3,4,5,6,7,8,9,10,11")
     ap.add_argument("--m", default="2438,4876")
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--shapes", default=None, help="name:N:K,... instead of the four TP=1 projection shapes")
     ap.add_argument("--check", action="store_true")
     ap.add_argument("--fill", default="randn", choices=["randn", "zeros", "ones"],
                     help="operand data: power (hence clock) depends on it — never quote a zero-fill number")
     ap.add_argument("--cold", type=int, default=6, help="rotate over this many operand copies (defeats the 256 MB MALL)")
     args = ap.parse_args()
+    shapes = SHAPES
+    if args.shapes:
+        shapes = {n: (int(a), int(b)) for n, a, b in (x.split(":") for x in args.shapes.split(","))}
     lib = abi.lib()
     dev = "cuda:0"
     variants = [int(v) for v in args.variants.split(",")]
     st = torch.cuda.current_stream().cuda_stream
     print(f"{'shape':8s} {'M':>5s} " + " ".join(f"v{v:<6d}" for v in variants) + "   (TFLOP/s, median)")
     for M in [int(m) for m in args.m.split(",")]:
-        for name, (N, K) in SHAPES.items():
+        for name, (N, K) in shapes.items():
             A = torch.randn(M, K, device=dev).to(torch.bfloat16)
             W = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
             if args.fill != "randn":
