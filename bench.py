@@ -95,6 +95,9 @@ def main():
     ap.add_argument("--timesteps", type=int, default=64, help="debug only")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (marks the line reduced)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parallelism", choices=["tp", "dp"], default="tp",
+                    help="tp (default, BASELINE configs[2]): the model is tensor-parallel over all ranks, batch = N jobs; "
+                         "dp: every rank holds the full 16 GB model and runs its own job, no data-path collective")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -120,9 +123,11 @@ def main():
         cfg["n_layers"] = args.layers
     reduced = args.text_steps != 128 or args.timesteps != 64 or args.layers is not None
     full = synth.full_config(cfg)
-    B = world  # weak scaling: one job per rank-equivalent, model tensor-parallel over all ranks
+    tp = world if args.parallelism == "tp" else 1
+    B = tp  # weak scaling: one job per rank-equivalent; tp: model sharded over all ranks, dp: replicas
     sd = synth.synthetic_state_dict(cfg, seed=0, device=str(dev))
-    model = LLaDAForMultiModalGeneration.from_state_dict(full, sd, device=dev, tp_rank=rank, tp_size=world, max_batch=2 * B)
+    model = LLaDAForMultiModalGeneration.from_state_dict(full, sd, device=dev, tp_rank=rank if tp > 1 else 0, tp_size=tp,
+                                                         max_batch=2 * B)
     del sd
     torch.cuda.empty_cache()
 
@@ -164,7 +169,7 @@ def main():
 
         n_img = len(set(image_step_indices(args.text_steps, args.timesteps)))
         fl_img = job_flops(cfg, L, T, N, args.text_steps, n_img, cfg["embedding_size"], synth.CODEBOOK)
-        images = args.steps * B
+        images = args.steps * world  # tp: B = world jobs in one group; dp: one job on each of `world` replicas
         value = images / dt
         kinds = {}
         for i, nm in enumerate(KIND_NAMES):
@@ -179,7 +184,7 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: MMaDA-Parallel-A 8B, 512x512, timesteps=64, text_steps=128, "
                                    "cfg_img=4.0, temperature=0, L=2438, 256 forwards/image" + (" [REDUCED DEBUG RUN]" if reduced else ""),
-                       "global_batch": B, "seq_len": L, "parallelism": f"tp{world}",
+                       "global_batch": world, "seq_len": L, "parallelism": f"{args.parallelism}{world}",
                        "text_steps": args.text_steps, "timesteps": args.timesteps, "n_layers": cfg["n_layers"],
                        "algorithmic_pflop_per_image": fl_img / 1e15,
                        "job_mfma_frac": value * fl_img / 1e12 / (world * MFMA_BF16_PEAK_TFLOPS),

@@ -184,6 +184,45 @@ int mmada_image_commit_m(mmada_handle* h, int64_t* ids, int B, int L, const int3
 int mmada_lfq_gather(mmada_handle* h, const int64_t* idx, int B, int N, int nbits, int dtype_f32, void* out,
                      void* stream);
 
+/* ---- MAGVITv2 token -> pixel decode of MMaDA-Parallel-M, fp32 like the reference -----------
+ * Replaces  vq_model.decode_code(output_image_ids)  (MMaDA-Parallel-M/inference.py:127, models/modeling_mmada.py:840):
+ * MAGVITv2.decode_code models/modeling_magvitv2.py:429-433 = LFQuantizer.get_codebook_entry :208-221 +
+ * VQGANDecoder.forward :369-406 (ResnetBlock / AttnBlock / Upsample / GroupNorm(32) / swish,
+ * models/common_modules.py:337-357,187-211,36-40,16-24).  Independent of mmada_handle (own weights, own workspace). */
+typedef struct mmada_vq mmada_vq;
+typedef struct mmada_vq_cfg {      /* VQGANDecoder.__init__ arguments, modeling_magvitv2.py:278-287 */
+    int32_t ch;                    /* 128; must be a multiple of 128 */
+    int32_t n_levels;              /* len(ch_mult) <= 8; the decoder upsamples by 2^(n_levels-1) */
+    int32_t ch_mult[8];            /* [1,1,2,2,4]; index 0 = full resolution */
+    int32_t num_res_blocks[8];     /* [4,4,3,4,3] */
+    int32_t z_channels;            /* 13 = LFQ codebook_dim (codebook size 2^13) */
+    int32_t out_ch;                /* 3 */
+} mmada_vq_cfg;
+int mmada_vq_create(const mmada_vq_cfg* cfg, mmada_vq** out);
+void mmada_vq_destroy(mmada_vq* h);
+/* Bind one tensor of the decoder's state dict by its checkpoint key ("conv_in.weight", "mid.block_1.norm1.bias",
+ * "up.3.block.0.nin_shortcut.weight", "up.2.upsample.conv.weight", ...; an optional "decoder." prefix is accepted).
+ * data: device fp32 in the nn.Module layout ([Cout,Cin,k,k] for convolutions); the library keeps its own repacked
+ * copy ([Cout][tap][Cin]).  Unknown keys and wrong element counts are errors. */
+int mmada_vq_bind(mmada_vq* h, const char* name, const float* data, int64_t numel, void* stream);
+int mmada_vq_num_unbound(const mmada_vq* h);   /* 0 when every expected tensor has been bound */
+size_t mmada_vq_workspace_bytes(const mmada_vq* h, int B, int hz, int wz);
+/* indices: device int64 [B, hz*wz] codebook ids; out: device fp32 [B, out_ch, hz*2^(n_levels-1), wz*2^(n_levels-1)]
+ * (NCHW, unclamped, exactly what decode_code returns).  workspace: device, 256-byte aligned,
+ * >= mmada_vq_workspace_bytes(h,B,hz,wz).  hz*wz must be a multiple of 32. */
+int mmada_vq_decode_code(mmada_vq* h, const int64_t* indices, int B, int hz, int wz, void* workspace,
+                         size_t workspace_bytes, float* out, void* stream);
+/* Kernel-level entry points (parity tests).  NHWC fp32; w_packed = weight.permute(0,2,3,1) ([Cout][k*k][Cin]);
+ * upsample != 0 folds F.interpolate(scale_factor=2, mode="nearest") in front of the convolution (Upsample.forward);
+ * resid (optional, may alias out) is added after the bias.  out: [B, Hi<<ups, Wi<<ups, Cout]. */
+int mmada_vq_conv2d(const float* in_nhwc, const float* w_packed, const float* bias, const float* resid, float* out,
+                    int B, int Hi, int Wi, int Cin, int Cout, int ksize, int upsample, void* stream);
+/* GroupNorm(32, C, eps=1e-6, affine) over NHWC [B, HW, C] (+ x*sigmoid(x) when swish != 0); C multiple of 128.
+ * scratch: device, >= mmada_vq_group_norm_scratch_bytes(B). */
+int mmada_vq_group_norm(const float* x_nhwc, const float* gamma, const float* beta, float* out, void* scratch,
+                        int B, int HW, int C, int swish, void* stream);
+size_t mmada_vq_group_norm_scratch_bytes(int B);
+
 /* ---- live kernel timing (bench.py's roofline leg) ---------------------------------------------------------------
  * While enabled, the five hot kernels of block `layer` (0 qkv GEMM+RoPE, 1 attention, 2 attn_out GEMM, 3 gate/up
  * GEMM+SiLU·mul, 4 down GEMM) are bracketed by hipEvents on the launch stream.  mmada_profile_end synchronises

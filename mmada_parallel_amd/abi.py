@@ -65,6 +65,15 @@ SIGNATURES = {
     "mmada_gemm_bt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mmada_gemm_variant": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mmada_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "mmada_vq_create": (c_int, [c_void_p, C.POINTER(c_void_p)]),
+    "mmada_vq_destroy": (None, [c_void_p]),
+    "mmada_vq_bind": (c_int, [c_void_p, C.c_char_p, c_void_p, C.c_int64, c_void_p]),
+    "mmada_vq_num_unbound": (c_int, [c_void_p]),
+    "mmada_vq_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int, c_int]),
+    "mmada_vq_decode_code": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mmada_vq_conv2d": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
+    "mmada_vq_group_norm": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
+    "mmada_vq_group_norm_scratch_bytes": (c_size_t, [c_int]),
     "mmada_sdpa": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 

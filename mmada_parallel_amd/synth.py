@@ -104,3 +104,64 @@ def synthetic_job(height: int = 512, width: int = 512, text_gen_length: int = 25
                 uncon_image=torch.tensor(uncon_image, dtype=torch.long).unsqueeze(0),
                 text_start=text_start, text_end=text_start + text_gen_length, image_start=image_start,
                 seq_len=seq_len, newline_every=newline_every)
+
+
+# ---- MAGVITv2 decoder of MMaDA-Parallel-M --------------------------------------------------------
+# Defaults of VQGANDecoder.__init__ (MMaDA-Parallel-M/models/modeling_magvitv2.py:278-287); level 0 = full resolution.
+VQ_CFG_M = dict(ch=128, ch_mult=[1, 1, 2, 2, 4], num_res_blocks=[4, 4, 3, 4, 3], z_channels=13, out_ch=3)
+VQ_CFG_TINY = dict(ch=128, ch_mult=[1, 2], num_res_blocks=[1, 2], z_channels=13, out_ch=3)
+
+
+def vq_decoder_param_shapes(cfg: dict) -> Dict[str, tuple]:
+    """State-dict keys and shapes of the reference VQGANDecoder for `cfg` (module tree modeling_magvitv2.py:305-367,
+    ResnetBlock common_modules.py:299-335, AttnBlock :168-185, Upsample :27-34)."""
+    ch, mult, nrb, zc = cfg["ch"], cfg["ch_mult"], cfg["num_res_blocks"], cfg["z_channels"]
+    out: Dict[str, tuple] = {}
+
+    def conv(p, co, ci, k):
+        out[p + ".weight"], out[p + ".bias"] = (co, ci, k, k), (co,)
+
+    def norm(p, c):
+        out[p + ".weight"], out[p + ".bias"] = (c,), (c,)
+
+    def res(p, ci, co):
+        norm(p + ".norm1", ci); conv(p + ".conv1", co, ci, 3)
+        norm(p + ".norm2", co); conv(p + ".conv2", co, co, 3)
+        if ci != co:
+            conv(p + ".nin_shortcut", co, ci, 1)
+
+    block_in = ch * mult[-1]
+    conv("conv_in", block_in, zc, 3)
+    res("mid.block_1", block_in, block_in)
+    norm("mid.attn_1.norm", block_in)
+    for n in ("q", "k", "v", "proj_out"):
+        conv("mid.attn_1." + n, block_in, block_in, 1)
+    res("mid.block_2", block_in, block_in)
+    for lvl in reversed(range(len(mult))):
+        block_out = ch * mult[lvl]
+        for b in range(nrb[lvl]):
+            res(f"up.{lvl}.block.{b}", block_in, block_out)
+            block_in = block_out
+        if lvl != 0:
+            conv(f"up.{lvl}.upsample.conv", block_in, block_in, 3)
+    norm("norm_out", block_in)
+    conv("conv_out", cfg["out_ch"], block_in, 3)
+    conv("post_quant_conv", zc, zc, 1)
+    return out
+
+
+def synthetic_vq_state_dict(cfg: dict, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded fp32 decoder weights (CPU generator, so every machine gets the same tensors): conv N(0, 1/fan_in),
+    conv bias N(0, 0.05²), GroupNorm weight 1+N(0, 0.1²), bias N(0, 0.1²)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+    for name, shape in vq_decoder_param_shapes(cfg).items():
+        if len(shape) == 4:
+            std = (shape[1] * shape[2] * shape[3]) ** -0.5
+            sd[name] = torch.randn(shape, generator=g) * std
+        elif ".norm" in name or name.startswith("norm_out"):
+            sd[name] = torch.randn(shape, generator=g) * 0.1 + (1.0 if name.endswith(".weight") else 0.0)
+        else:
+            sd[name] = torch.randn(shape, generator=g) * 0.05
+    return sd

@@ -14,6 +14,9 @@ Fixtures
                      sampler passes to every model call + final outputs — generators/parallel_generator.py:102-368
   e2e_tiny.npz       generate_ti2ti with the real tiny model at temperature 0: ids at every model call + outputs
   logconf_table.npy  torch.log(p + 1e-10) in bf16 for every non-negative bf16 p (parallel_generator.py:36)
+  vq_decode.npz      MMaDA-Parallel-M MAGVITv2.decode_code (LFQuantizer.get_codebook_entry + VQGANDecoder, fp32) on
+                     seeded synthetic decoder weights: a 2-level decoder (full output) and the default 5-level
+                     decoder at 32x32 codes -> 512x512 (every 4th pixel) — models/modeling_magvitv2.py:208-221,277-433
 """
 from __future__ import annotations
 
@@ -300,6 +303,55 @@ def gen_stepwise_traj():
     np.savez_compressed(os.path.join(OUT, "stepwise_traj.npz"), **out)
 
 
+def gen_vq_decode():
+    """Runs the reference's own MAGVITv2.decode_code on its own LFQuantizer / VQGANDecoder modules.  Only
+    models/modeling_utils.py (the HF ModelMixin clone: checkpoint IO, no arithmetic; needs diffusers/omegaconf) is
+    replaced by plain nn.Module mixins, and the unused encoder is not instantiated."""
+    import importlib
+    import types
+    from unittest import mock
+
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [M_REF + "/models"]
+    saved = {k: sys.modules.get(k) for k in ("models", "models.modeling_utils")}
+    sys.modules["models"] = pkg
+    for name in ("omegaconf", "jaxtyping", "typeguard"):
+        if name not in sys.modules:
+            sys.modules[name] = mock.MagicMock()
+    mu = types.ModuleType("models.modeling_utils")
+    mu.ConfigMixin = type("ConfigMixin", (), {})
+    mu.ModelMixin = type("ModelMixin", (torch.nn.Module,), {})
+    mu.register_to_config = lambda f: f
+    sys.modules["models.modeling_utils"] = mu
+    mv = importlib.import_module("models.modeling_magvitv2")
+    out = {}
+    for name, cfg, B, hz in (("tiny", synth.VQ_CFG_TINY, 2, 8), ("full", synth.VQ_CFG_M, 1, 32)):
+        seed = 7 if name == "tiny" else 8
+        sd = synth.synthetic_vq_state_dict(cfg, seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            dec = mv.VQGANDecoder(ch=cfg["ch"], ch_mult=cfg["ch_mult"], num_res_blocks=cfg["num_res_blocks"],
+                                  z_channels=cfg["z_channels"], out_ch=cfg["out_ch"])
+            quant = mv.LFQuantizer(codebook_dim=cfg["z_channels"])
+        dec.load_state_dict(sd, strict=True)
+        dec.eval()
+        g = torch.Generator().manual_seed(100 + seed)
+        idx = torch.randint(0, 2 ** cfg["z_channels"], (B, hz * hz), generator=g)
+        with torch.no_grad():
+            img = mv.MAGVITv2.decode_code(SimpleNamespace(quantize=quant, decoder=dec), idx)
+        out[name + "_idx"] = idx.numpy()
+        out[name + "_seed"] = np.array(seed)
+        out[name + "_out"] = (img if name == "tiny" else img[:, :, ::4, ::4]).contiguous().numpy()
+        out[name + "_stats"] = np.array([img.mean().item(), img.std().item(), img.abs().max().item()])
+        print(f"vq_decode[{name}]: {tuple(idx.shape)} -> {tuple(img.shape)}, std {img.std().item():.4f}")
+    np.savez_compressed(os.path.join(OUT, "vq_decode.npz"), **out)
+    for k, v in saved.items():
+        sys.modules.pop(k, None)
+        if v is not None:
+            sys.modules[k] = v
+    for k in [k for k in sys.modules if k.startswith("models.")]:
+        sys.modules.pop(k, None)
+
+
 def gen_tables():
     b = torch.arange(0, 0x7f80, dtype=torch.int32).to(torch.int16)
     np.save(os.path.join(OUT, "logconf_table.npy"), torch.log(b.view(torch.bfloat16) + 1e-10).view(torch.int16).numpy())
@@ -309,7 +361,13 @@ if __name__ == "__main__":
     if not os.path.isdir(REF):
         sys.exit("reference not mounted at " + REF)
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1:]
+    if only:  # e.g. `python oracle/gen_golden.py gen_vq_decode` regenerates one fixture
+        for fn in only:
+            globals()[fn]()
+        sys.exit(0)
     gen_tables()
+    gen_vq_decode()
     gen_stepwise_traj()
     gen_m_traj()
     gen_sampler_traj()

@@ -204,3 +204,34 @@ def test_stepwise_trajectory_matches_reference(name):
                              cfg_img=kw["cfg_img"], uncon_text=job["uncon_text"], uncon_image=job["uncon_image"],
                              text_vocab_size=STUB_TEXT_VOCAB, codebook_size=STUB_CB, trace=trace, image_step_list=sched)
     assert torch.equal(torch.cat(trace, 0), torch.from_numpy(z[name + "_calls"]))
+
+
+# ---- MAGVITv2 decode (MMaDA-Parallel-M models/modeling_magvitv2.py:208-221,277-433), fp32 -----------------------------
+@pytest.mark.parametrize("name", ["tiny", "full"])
+def test_vq_decode_oracle_matches_reference(name):
+    """oracle/vq_oracle.py restates LFQuantizer.get_codebook_entry + VQGANDecoder.forward; the fixture is the output of
+    the reference's own modules on the same seeded weights.  Same torch CPU ops in the same order: tolerance covers
+    only thread-count-dependent conv blocking (<= 2e-5 of the output range)."""
+    from oracle import vq_oracle
+
+    z = np.load(os.path.join(GOLDEN, "vq_decode.npz"))
+    cfg = synth.VQ_CFG_TINY if name == "tiny" else synth.VQ_CFG_M
+    sd = synth.synthetic_vq_state_dict(cfg, int(z[name + "_seed"]))
+    img = vq_oracle.decode_code(sd, cfg, torch.from_numpy(z[name + "_idx"]))
+    ref = torch.from_numpy(z[name + "_out"])
+    got = img if name == "tiny" else img[:, :, ::4, ::4]
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    stats = z[name + "_stats"]
+    assert abs(img.std().item() - stats[1]) < 1e-5 and abs(img.abs().max().item() - stats[2]) < 1e-4
+
+
+def test_lfq_codebook_entry_is_the_bit_pattern():
+    from oracle import vq_oracle
+
+    idx = torch.tensor([[0, 1, 4096, 8191]])
+    z = vq_oracle.lfq_codebook_entry(idx, 13, shape=(2, 2))  # [1, 13, 2, 2]; channel 0 = MSB
+    assert z[0, :, 0, 0].tolist() == [-1.0] * 13
+    assert z[0, :, 0, 1].tolist() == [-1.0] * 12 + [1.0]
+    assert z[0, :, 1, 0].tolist() == [1.0] + [-1.0] * 12
+    assert z[0, :, 1, 1].tolist() == [1.0] * 13
