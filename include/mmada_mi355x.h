@@ -212,9 +212,22 @@ size_t mmada_vq_workspace_bytes(const mmada_vq* h, int B, int hz, int wz);
  * >= mmada_vq_workspace_bytes(h,B,hz,wz).  hz*wz must be a multiple of 32. */
 int mmada_vq_decode_code(mmada_vq* h, const int64_t* indices, int B, int hz, int wz, void* workspace,
                          size_t workspace_bytes, float* out, void* stream);
+/* Encoder direction: replaces  vq_model.get_code(image)  (MMaDA-Parallel-M/inference.py:79; MAGVITv2.get_code
+ * models/modeling_magvitv2.py:422-427 = VQGANEncoder.forward :143-171 + the sign quantisation / get_indices of
+ * LFQuantizer :201-206,241-243).  cfg as for the decoder with the encoder's ch_mult / num_res_blocks
+ * ([1,2,2,4,4] / [4,3,4,3,4], :63-66) and out_ch = the image channel count (3).  Bind "encoder.*" / bare keys
+ * ("conv_in.weight", "down.1.block.0.nin_shortcut.weight", "down.0.downsample.conv.weight", "quant_conv.weight", ...)
+ * with mmada_vq_bind; workspace from mmada_vq_workspace_bytes(h, B, H/2^(n_levels-1), W/2^(n_levels-1)). */
+int mmada_vq_create_encoder(const mmada_vq_cfg* cfg, mmada_vq** out);
+/* pixel_values: device fp32 [B, out_ch, H, W] (NCHW, normalised to [-1,1] by the caller);  indices_out: device int64
+ * [B, (H/f)*(W/f)], f = 2^(n_levels-1), bit (z_channels-1-c) of an index = (z_c > 0);  z_out (optional): device fp32
+ * [B, (H/f)*(W/f), z_channels], the pre-quantisation encoder output (parity tap). */
+int mmada_vq_get_code(mmada_vq* h, const float* pixel_values, int B, int H, int W, void* workspace,
+                      size_t workspace_bytes, int64_t* indices_out, float* z_out, void* stream);
 /* Kernel-level entry points (parity tests).  NHWC fp32; w_packed = weight.permute(0,2,3,1) ([Cout][k*k][Cin]);
- * upsample != 0 folds F.interpolate(scale_factor=2, mode="nearest") in front of the convolution (Upsample.forward);
- * resid (optional, may alias out) is added after the bias.  out: [B, Hi<<ups, Wi<<ups, Cout]. */
+ * upsample > 0 folds F.interpolate(scale_factor=2, mode="nearest") in front of the convolution (Upsample.forward),
+ * upsample < 0 is Downsample.forward (F.pad(x,(0,1,0,1)) + 3x3 stride 2, common_modules.py:83-90);
+ * resid (optional, may alias out) is added after the bias.  out: [B, Ho, Wo, Cout]. */
 int mmada_vq_conv2d(const float* in_nhwc, const float* w_packed, const float* bias, const float* resid, float* out,
                     int B, int Hi, int Wi, int Cin, int Cout, int ksize, int upsample, void* stream);
 /* GroupNorm(32, C, eps=1e-6, affine) over NHWC [B, HW, C] (+ x*sigmoid(x) when swish != 0); C multiple of 128.

@@ -31,9 +31,25 @@ struct ConvArgs {
     const float* bias;   // [Cout] or null
     const float* resid;  // [B, Ho, Wo, Cout] or null (may alias out)
     float* out;          // [B, Ho, Wo, Cout]  (nchw_out: [B, Cout, Ho, Wo], direct kernel only)
-    int B, Hi, Wi, Cin, Cout, Ho, Wo, taps, ups, nchw_out;
+    int B, Hi, Wi, Cin, Cout, Ho, Wo, taps, ups, down, nchw_out;
     long long M;         // B * Ho * Wo
 };
+
+// Input pixel of output pixel (oh, ow) for filter tap `tap`; false = zero padding.
+//   default: stride 1, padding k/2 (Conv2d(k, 1, k//2))
+//   ups:     the same on the 2x nearest-upsampled input (Upsample.forward, common_modules.py:36-40)
+//   down:    Downsample.forward (common_modules.py:83-90): F.pad(x, (0,1,0,1)) then Conv2d(3, stride 2, padding 0)
+MM_DEVICE bool conv_src(const ConvArgs& g, int oh, int ow, int tap, int& ih, int& iw) {
+    if (g.down) {
+        ih = 2 * oh + tap / 3;
+        iw = 2 * ow + tap % 3;
+        return ih < g.Hi && iw < g.Wi;
+    }
+    const int uh = oh + (g.taps == 9 ? tap / 3 - 1 : 0), uw = ow + (g.taps == 9 ? tap % 3 - 1 : 0);
+    ih = uh >> g.ups;
+    iw = uw >> g.ups;
+    return uh >= 0 && uh < g.Ho && uw >= 0 && uw < g.Wo;
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Implicit-GEMM convolution on the fp32 matrix cores.  256 threads = 4 waves (2x2), wave tile 64x64 = 2x2 MFMA
@@ -73,14 +89,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs g) {
     f32x4 ra[4], rb[4];
     auto gload = [&](int ch) {
         const int tap = ch / cchunks, c0 = (ch - tap * cchunks) * CBK;
-        const int dy = g.taps == 9 ? tap / 3 - 1 : 0, dx = g.taps == 9 ? tap % 3 - 1 : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int ih = poh[i] + dy, iw = pow_[i] + dx;
-            const bool ok = pv[i] && ih >= 0 && ih < g.Ho && iw >= 0 && iw < g.Wo;
+            int ih, iw;
+            const bool ok = conv_src(g, poh[i], pow_[i], tap, ih, iw) && pv[i];
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok)
-                v = *(const f32x4*)(g.in + (((size_t)pb[i] * g.Hi + (ih >> g.ups)) * g.Wi + (iw >> g.ups)) * g.Cin + c0 + 4 * lc);
+            if (ok) v = *(const f32x4*)(g.in + (((size_t)pb[i] * g.Hi + ih) * g.Wi + iw) * g.Cin + c0 + 4 * lc);
             ra[i] = v;
             f32x4 wv4 = {0.f, 0.f, 0.f, 0.f};
             if (wv[i]) wv4 = *(const f32x4*)(wrow[i] + (size_t)tap * g.Cin + c0);
@@ -156,10 +170,9 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(ConvArgs g) {
     for (int c = 0; c < CO; ++c) acc[c] = 0.f;
     const size_t wstride = (size_t)g.taps * g.Cin;
     for (int tap = 0; tap < g.taps; ++tap) {
-        const int dy = g.taps == 9 ? tap / 3 - 1 : 0, dx = g.taps == 9 ? tap % 3 - 1 : 0;
-        const int ih = oh + dy, iw = ow + dx;
-        if (ih < 0 || ih >= g.Ho || iw < 0 || iw >= g.Wo) continue;
-        const float* src = g.in + (((size_t)b * g.Hi + (ih >> g.ups)) * g.Wi + (iw >> g.ups)) * g.Cin;
+        int ih, iw;
+        if (!conv_src(g, oh, ow, tap, ih, iw)) continue;
+        const float* src = g.in + (((size_t)b * g.Hi + ih) * g.Wi + iw) * g.Cin;
         const float* wt = g.w + (size_t)co0 * wstride + (size_t)tap * g.Cin;
         for (int ci = 0; ci < g.Cin; ++ci) {
             const float x = src[ci];
@@ -200,10 +213,9 @@ __global__ __launch_bounds__(256) void conv_thin_kernel(ConvArgs g) {
     float acc[THIN_CO] = {0.f, 0.f, 0.f, 0.f};
     const int wstride = g.taps * g.Cin;
     for (int tap = 0; tap < g.taps; ++tap) {
-        const int dy = g.taps == 9 ? tap / 3 - 1 : 0, dx = g.taps == 9 ? tap % 3 - 1 : 0;
-        const int ih = oh + dy, iw = ow + dx;
-        if (!live || ih < 0 || ih >= g.Ho || iw < 0 || iw >= g.Wo) continue;
-        const float* src = g.in + (((size_t)b * g.Hi + (ih >> g.ups)) * g.Wi + (iw >> g.ups)) * g.Cin;
+        int ih, iw;
+        if (!conv_src(g, oh, ow, tap, ih, iw) || !live) continue;
+        const float* src = g.in + (((size_t)b * g.Hi + ih) * g.Wi + iw) * g.Cin;
         for (int c = sub * 4; c < g.Cin; c += 32) {
             const f32x4 x = *(const f32x4*)(src + c);
 #pragma unroll
@@ -348,6 +360,24 @@ __global__ void lfq_nhwc_kernel(const int64_t* __restrict__ idx, float* __restri
     for (int c = 0; c < nbits; ++c) out[i * nbits + c] = ((v >> (nbits - 1 - c)) & 1) ? 1.0f : -1.0f;
 }
 
+// LFQuantizer.get_indices (modeling_magvitv2.py:201-206) of the sign quantisation (:241-243): bit (nbits-1-c) = z_c > 0
+__global__ void lfq_index_kernel(const float* __restrict__ z, int64_t* __restrict__ idx, long long n, int nbits) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    long long v = 0;
+    for (int c = 0; c < nbits; ++c) v |= (long long)(z[i * nbits + c] > 0.f) << (nbits - 1 - c);
+    idx[i] = v;
+}
+
+// pixel_values [B, C, HW] -> [B, HW, C]
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, long long HW, long long total) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const long long b = i / (HW * C), r = i - b * HW * C, p = r / C;
+    const int c = (int)(r - p * C);
+    out[i] = in[(b * C + c) * HW + p];
+}
+
 // [Cout][Cin][k][k] (nn.Conv2d) -> [Cout][k*k][Cin]
 __global__ void repack_conv_kernel(const float* __restrict__ src, float* __restrict__ dst, int co, int ci, int kk) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -422,8 +452,9 @@ struct mmada_vq {
     ConvP post_quant, conv_in, conv_out, aq, ak, av, aproj;
     NormP norm_out, attn_norm;
     ResP mid1, mid2;
-    std::vector<std::vector<ResP>> up;  // [level][block]
-    std::vector<ConvP> upsample;        // [level] (level 0 unused)
+    std::vector<std::vector<ResP>> up;  // [level][block]   (decoder: up.*, encoder: down.*)
+    std::vector<ConvP> upsample;        // [level] decoder: up.{l}.upsample.conv (l > 0); encoder: down.{l}.downsample.conv
+    bool encoder = false;               // encoder: conv_in takes cfg.out_ch image channels, post_quant = quant_conv
     std::map<std::string, Slot> slots;
     std::vector<float*> owned;
 };
@@ -460,16 +491,15 @@ struct Plan {
 
 Plan plan_for(const mmada_vq* h, int B, int hz, int wz) {
     const mmada_vq_cfg& c = h->cfg;
-    size_t max_elems = (size_t)hz * wz * c.ch * c.ch_mult[c.n_levels - 1];
-    int H = hz, W = wz;
-    for (int lvl = c.n_levels - 1; lvl >= 0; --lvl) {
-        const size_t ch = (size_t)c.ch * c.ch_mult[lvl];
-        const size_t chin = lvl == c.n_levels - 1 ? ch : (size_t)c.ch * c.ch_mult[lvl + 1];
-        max_elems = std::max(max_elems, (size_t)H * W * std::max(ch, chin));
-        if (lvl != 0) {
-            H *= 2; W *= 2;
-            max_elems = std::max(max_elems, (size_t)H * W * ch);
-        }
+    // largest [H, W, C] of the network: level l lives at hz * 2^(L-1-l); a tensor at that resolution has the channel
+    // count of level l or of a neighbouring level (first block of a level / tensor just after a resample)
+    size_t max_elems = 0;
+    for (int lvl = 0; lvl < c.n_levels; ++lvl) {
+        int m = c.ch_mult[lvl];
+        if (lvl > 0) m = std::max(m, c.ch_mult[lvl - 1]);
+        if (lvl + 1 < c.n_levels) m = std::max(m, c.ch_mult[lvl + 1]);
+        const size_t f = (size_t)1 << (c.n_levels - 1 - lvl);
+        max_elems = std::max(max_elems, (size_t)hz * f * wz * f * c.ch * m);
     }
     Plan p;
     p.act_bytes = align256(max_elems * B * sizeof(float));
@@ -484,13 +514,45 @@ struct Runner {
     hipStream_t s;
     double* gn;
     int B;
-    int conv(const ConvP& p, const float* in, float* out, const float* resid, int Hi, int Wi, int ups, int nchw = 0) {
+    // resample: 0 same size, 1 = 2x nearest upsample folded in front, -1 = Downsample (pad right/bottom, stride 2)
+    int conv(const ConvP& p, const float* in, float* out, const float* resid, int Hi, int Wi, int resample, int nchw = 0) {
         ConvArgs g{};
         g.in = in; g.w = p.w; g.bias = p.b; g.resid = resid; g.out = out;
-        g.B = B; g.Hi = Hi; g.Wi = Wi; g.Cin = p.ci; g.Cout = p.co; g.Ho = Hi << ups; g.Wo = Wi << ups;
-        g.taps = p.k * p.k; g.ups = ups; g.nchw_out = nchw;
+        g.B = B; g.Hi = Hi; g.Wi = Wi; g.Cin = p.ci; g.Cout = p.co;
+        g.ups = resample > 0; g.down = resample < 0;
+        g.Ho = g.down ? (Hi - 2) / 2 + 1 : Hi << g.ups;
+        g.Wo = g.down ? (Wi - 2) / 2 + 1 : Wi << g.ups;
+        g.taps = p.k * p.k; g.nchw_out = nchw;
         g.M = (long long)B * g.Ho * g.Wo;
         return launch_conv(g, s);
+    }
+    // AttnBlock.forward (common_modules.py:187-211): x += proj_out(softmax(q k^T / sqrt(C)) v), single head over H*W
+    int attn(const mmada_vq* h, float* x, float* t1, float* scratch, int H, int W) {
+        const int T = H * W, C = h->attn_norm.c;
+        float* q = scratch;
+        float* k = q + (size_t)B * T * C;
+        float* v = k + (size_t)B * T * C;
+        float* vt = v + (size_t)B * T * C;   // one batch element at a time: [C, T]
+        float* S = vt + (size_t)B * T * C;   // [T, T]
+        if (norm(h->attn_norm, x, t1, T, 0)) return 1;
+        if (conv(h->aq, t1, q, nullptr, H, W, 0)) return 1;
+        if (conv(h->ak, t1, k, nullptr, H, W, 0)) return 1;
+        if (conv(h->av, t1, v, nullptr, H, W, 0)) return 1;
+        for (int b = 0; b < B; ++b) {
+            ConvArgs g{};
+            g.in = q + (size_t)b * T * C; g.w = k + (size_t)b * T * C; g.out = S;
+            g.B = 1; g.Hi = g.Ho = T; g.Wi = g.Wo = 1; g.Cin = C; g.Cout = T; g.taps = 1; g.M = T;
+            if (launch_conv(g, s)) return 1;  // S[i][j] = sum_c q[i][c] k[j][c]
+            hipLaunchKernelGGL(softmax_rows_kernel, dim3(T), dim3(256), 0, s, S, T, 1.0f / sqrtf((float)C));
+            hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (T + 31) / 32), dim3(256), 0, s,
+                               v + (size_t)b * T * C, vt, T, C);
+            MM_CHECK_HIP(hipGetLastError());
+            ConvArgs o{};
+            o.in = S; o.w = vt; o.out = t1 + (size_t)b * T * C;
+            o.B = 1; o.Hi = o.Ho = T; o.Wi = o.Wo = 1; o.Cin = T; o.Cout = C; o.taps = 1; o.M = T;
+            if (launch_conv(o, s)) return 1;  // h_[i][c] = sum_j softmax(S)[i][j] v[j][c]
+        }
+        return conv(h->aproj, t1, x, x, H, W, 0);
     }
     int norm(const NormP& n, const float* in, float* out, int HW, int swish) {
         return launch_group_norm(in, n.g, n.b, out, gn, B, HW, n.c, swish, s);
@@ -512,7 +574,7 @@ struct Runner {
 
 extern "C" {
 
-int mmada_vq_create(const mmada_vq_cfg* cfg, mmada_vq** out) {
+static int vq_check_cfg(const mmada_vq_cfg* cfg, mmada_vq** out) {
     if (!cfg || !out) return mm_fail("mmada_vq_create: null argument");
     if (cfg->n_levels < 1 || cfg->n_levels > 8) return mm_fail("mmada_vq_create: n_levels must be 1..8");
     if (cfg->ch <= 0 || cfg->ch % 128) return mm_fail("mmada_vq_create: ch must be a positive multiple of 128 (GroupNorm(32) over float4 columns)");
@@ -521,6 +583,11 @@ int mmada_vq_create(const mmada_vq_cfg* cfg, mmada_vq** out) {
     for (int i = 0; i < cfg->n_levels; ++i)
         if (cfg->ch_mult[i] <= 0 || cfg->num_res_blocks[i] <= 0 || cfg->ch * cfg->ch_mult[i] > 1024)
             return mm_fail("mmada_vq_create: bad ch_mult / num_res_blocks at level %d", i);
+    return 0;
+}
+
+int mmada_vq_create(const mmada_vq_cfg* cfg, mmada_vq** out) {
+    if (vq_check_cfg(cfg, out)) return 1;
     mmada_vq* h = new mmada_vq();
     h->cfg = *cfg;
     const int L = cfg->n_levels;
@@ -551,6 +618,40 @@ int mmada_vq_create(const mmada_vq_cfg* cfg, mmada_vq** out) {
     return 0;
 }
 
+/* VQGANEncoder.__init__ (modeling_magvitv2.py:62-141); cfg->out_ch carries in_ch (image channels) */
+int mmada_vq_create_encoder(const mmada_vq_cfg* cfg, mmada_vq** out) {
+    if (vq_check_cfg(cfg, out)) return 1;
+    mmada_vq* h = new mmada_vq();
+    h->cfg = *cfg;
+    h->encoder = true;
+    const int L = cfg->n_levels;
+    reg_conv(h, "conv_in", h->conv_in, cfg->ch, cfg->out_ch, 3);
+    h->up.resize(L);
+    h->upsample.resize(L);
+    int block_in = cfg->ch;
+    for (int lvl = 0; lvl < L; ++lvl) {
+        const int block_out = cfg->ch * cfg->ch_mult[lvl];
+        h->up[lvl].resize(cfg->num_res_blocks[lvl]);
+        for (int b = 0; b < cfg->num_res_blocks[lvl]; ++b) {
+            reg_res(h, "down." + std::to_string(lvl) + ".block." + std::to_string(b), h->up[lvl][b], block_in, block_out);
+            block_in = block_out;
+        }
+        if (lvl != L - 1) reg_conv(h, "down." + std::to_string(lvl) + ".downsample.conv", h->upsample[lvl], block_in, block_in, 3);
+    }
+    reg_res(h, "mid.block_1", h->mid1, block_in, block_in);
+    reg_norm(h, "mid.attn_1.norm", h->attn_norm, block_in);
+    reg_conv(h, "mid.attn_1.q", h->aq, block_in, block_in, 1);
+    reg_conv(h, "mid.attn_1.k", h->ak, block_in, block_in, 1);
+    reg_conv(h, "mid.attn_1.v", h->av, block_in, block_in, 1);
+    reg_conv(h, "mid.attn_1.proj_out", h->aproj, block_in, block_in, 1);
+    reg_res(h, "mid.block_2", h->mid2, block_in, block_in);
+    reg_norm(h, "norm_out", h->norm_out, block_in);
+    reg_conv(h, "conv_out", h->conv_out, cfg->z_channels, block_in, 3);
+    reg_conv(h, "quant_conv", h->post_quant, cfg->z_channels, cfg->z_channels, 1);
+    *out = h;
+    return 0;
+}
+
 void mmada_vq_destroy(mmada_vq* h) {
     if (!h) return;
     for (float* p : h->owned) (void)hipFree(p);
@@ -560,7 +661,8 @@ void mmada_vq_destroy(mmada_vq* h) {
 int mmada_vq_bind(mmada_vq* h, const char* name, const float* data, int64_t numel, void* stream) {
     if (!h || !name || !data) return mm_fail("mmada_vq_bind: null argument");
     std::string key(name);
-    if (key.rfind("decoder.", 0) == 0) key = key.substr(8);
+    const std::string prefix = h->encoder ? "encoder." : "decoder.";
+    if (key.rfind(prefix, 0) == 0) key = key.substr(prefix.size());
     auto it = h->slots.find(key);
     if (it == h->slots.end()) return mm_fail("mmada_vq_bind: unexpected tensor '%s'", name);
     Slot& sl = it->second;
@@ -591,12 +693,13 @@ int mmada_vq_num_unbound(const mmada_vq* h) {
 
 size_t mmada_vq_workspace_bytes(const mmada_vq* h, int B, int hz, int wz) {
     if (!h || B <= 0 || hz <= 0 || wz <= 0) return 0;
-    return plan_for(h, B, hz, wz).total;
+    return plan_for(h, B, hz, wz).total;  // encoder: the same buffers (largest activation is at the image resolution)
 }
 
 int mmada_vq_decode_code(mmada_vq* h, const int64_t* indices, int B, int hz, int wz, void* workspace,
                          size_t workspace_bytes, float* out, void* stream) {
     if (!h || !indices || !workspace || !out) return mm_fail("mmada_vq_decode_code: null argument");
+    if (h->encoder) return mm_fail("mmada_vq_decode_code: this handle is an encoder");
     if (B <= 0 || hz <= 0 || wz <= 0) return mm_fail("mmada_vq_decode_code: bad shape");
     if ((hz * wz) % 32) return mm_fail("mmada_vq_decode_code: hz*wz must be a multiple of 32 (attention K tiles)");
     for (const auto& kv : h->slots)
@@ -622,33 +725,7 @@ int mmada_vq_decode_code(mmada_vq* h, const int64_t* indices, int B, int hz, int
     if (r.conv(h->conv_in, t2, x, nullptr, H, W, 0)) return 1;
     // middle (:380-382)
     if (r.res(h->mid1, x, t1, t2, H, W)) return 1;
-    {
-        const int T = H * W, C = h->attn_norm.c;
-        float* q = attn;
-        float* k = q + (size_t)B * T * C;
-        float* v = k + (size_t)B * T * C;
-        float* vt = v + (size_t)B * T * C;   // one batch element at a time: [C, T]
-        float* S = vt + (size_t)B * T * C;   // [T, T]
-        if (r.norm(h->attn_norm, x, t1, T, 0)) return 1;
-        if (r.conv(h->aq, t1, q, nullptr, H, W, 0)) return 1;
-        if (r.conv(h->ak, t1, k, nullptr, H, W, 0)) return 1;
-        if (r.conv(h->av, t1, v, nullptr, H, W, 0)) return 1;
-        for (int b = 0; b < B; ++b) {
-            ConvArgs g{};
-            g.in = q + (size_t)b * T * C; g.w = k + (size_t)b * T * C; g.out = S;
-            g.B = 1; g.Hi = g.Ho = T; g.Wi = g.Wo = 1; g.Cin = C; g.Cout = T; g.taps = 1; g.M = T;
-            if (launch_conv(g, s)) return 1;  // S[i][j] = sum_c q[i][c] k[j][c]
-            hipLaunchKernelGGL(softmax_rows_kernel, dim3(T), dim3(256), 0, s, S, T, 1.0f / sqrtf((float)C));
-            hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (T + 31) / 32), dim3(256), 0, s,
-                               v + (size_t)b * T * C, vt, T, C);
-            MM_CHECK_HIP(hipGetLastError());
-            ConvArgs o{};
-            o.in = S; o.w = vt; o.out = t1 + (size_t)b * T * C;
-            o.B = 1; o.Hi = o.Ho = T; o.Wi = o.Wo = 1; o.Cin = T; o.Cout = C; o.taps = 1; o.M = T;
-            if (launch_conv(o, s)) return 1;  // h_[i][c] = sum_j softmax(S)[i][j] v[j][c]
-        }
-        if (r.conv(h->aproj, t1, x, x, H, W, 0)) return 1;
-    }
+    if (r.attn(h, x, t1, attn, H, W)) return 1;
     if (r.res(h->mid2, x, t1, t2, H, W)) return 1;
     // upsampling (:385-391)
     for (int lvl = c.n_levels - 1; lvl >= 0; --lvl) {
@@ -665,6 +742,56 @@ int mmada_vq_decode_code(mmada_vq* h, const int64_t* indices, int B, int hz, int
     return r.conv(h->conv_out, t1, out, nullptr, H, W, 0, 1);
 }
 
+/* MAGVITv2.get_code (modeling_magvitv2.py:422-427): VQGANEncoder.forward (:143-171) -> sign quantisation -> indices */
+int mmada_vq_get_code(mmada_vq* h, const float* pixel_values, int B, int H, int W, void* workspace,
+                      size_t workspace_bytes, int64_t* indices_out, float* z_out, void* stream) {
+    if (!h || !pixel_values || !workspace || !indices_out) return mm_fail("mmada_vq_get_code: null argument");
+    if (!h->encoder) return mm_fail("mmada_vq_get_code: this handle is a decoder");
+    const mmada_vq_cfg& c = h->cfg;
+    const int f = 1 << (c.n_levels - 1);
+    if (B <= 0 || H <= 0 || W <= 0 || H % f || W % f) return mm_fail("mmada_vq_get_code: H, W must be multiples of %d", f);
+    const int hz = H / f, wz = W / f;
+    if ((hz * wz) % 32) return mm_fail("mmada_vq_get_code: (H/%d)*(W/%d) must be a multiple of 32 (attention K tiles)", f, f);
+    for (const auto& kv : h->slots)
+        if (!kv.second.bound) return mm_fail("mmada_vq_get_code: tensor '%s' was never bound", kv.first.c_str());
+    const Plan pl = plan_for(h, B, hz, wz);
+    if (workspace_bytes < pl.total) return mm_fail("mmada_vq_get_code: workspace too small (%zu < %zu)", workspace_bytes, pl.total);
+    if ((uintptr_t)workspace & 255) return mm_fail("mmada_vq_get_code: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* x = (float*)ws;
+    float* t1 = (float*)(ws + pl.act_bytes);
+    float* t2 = (float*)(ws + 2 * pl.act_bytes);
+    float* attn = (float*)(ws + 3 * pl.act_bytes);
+    Runner r{s, (double*)(ws + 3 * pl.act_bytes + pl.attn_bytes), B};
+    const long long total = (long long)B * H * W * c.out_ch;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, pixel_values, t1,
+                       c.out_ch, (long long)H * W, total);
+    MM_CHECK_HIP(hipGetLastError());
+    if (r.conv(h->conv_in, t1, x, nullptr, H, W, 0)) return 1;
+    int Hc = H, Wc = W;
+    for (int lvl = 0; lvl < c.n_levels; ++lvl) {  // downsampling (:148-156); hs[-1] is always the running tensor
+        for (const ResP& rb : h->up[lvl])
+            if (r.res(rb, x, t1, t2, Hc, Wc)) return 1;
+        if (lvl != c.n_levels - 1) {
+            if (r.conv(h->upsample[lvl], x, t1, nullptr, Hc, Wc, -1)) return 1;
+            std::swap(x, t1);
+            Hc /= 2; Wc /= 2;
+        }
+    }
+    if (r.res(h->mid1, x, t1, t2, Hc, Wc)) return 1;  // middle (:159-162)
+    if (r.attn(h, x, t1, attn, Hc, Wc)) return 1;
+    if (r.res(h->mid2, x, t1, t2, Hc, Wc)) return 1;
+    if (r.norm(h->norm_out, x, t1, Hc * Wc, 1)) return 1;  // end (:165-169)
+    if (r.conv(h->conv_out, t1, t2, nullptr, Hc, Wc, 0)) return 1;
+    if (r.conv(h->post_quant, t2, t1, nullptr, Hc, Wc, 0)) return 1;  // quant_conv
+    const long long npix = (long long)B * Hc * Wc;
+    hipLaunchKernelGGL(lfq_index_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, t1, indices_out, npix, c.z_channels);
+    MM_CHECK_HIP(hipGetLastError());
+    if (z_out) MM_CHECK_HIP(hipMemcpyAsync(z_out, t1, (size_t)npix * c.z_channels * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
 /* kernel-level entry points (parity tests) */
 int mmada_vq_conv2d(const float* in_nhwc, const float* w_packed, const float* bias, const float* resid, float* out,
                     int B, int Hi, int Wi, int Cin, int Cout, int ksize, int upsample, void* stream) {
@@ -672,8 +799,11 @@ int mmada_vq_conv2d(const float* in_nhwc, const float* w_packed, const float* bi
     if (ksize != 1 && ksize != 3) return mm_fail("mmada_vq_conv2d: ksize must be 1 or 3");
     ConvArgs g{};
     g.in = in_nhwc; g.w = w_packed; g.bias = bias; g.resid = resid; g.out = out;
-    g.B = B; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.Cout = Cout; g.ups = upsample ? 1 : 0;
-    g.Ho = Hi << g.ups; g.Wo = Wi << g.ups; g.taps = ksize * ksize;
+    g.B = B; g.Hi = Hi; g.Wi = Wi; g.Cin = Cin; g.Cout = Cout; g.ups = upsample > 0; g.down = upsample < 0;
+    if (g.down && ksize != 3) return mm_fail("mmada_vq_conv2d: the stride-2 mode is 3x3 only");
+    g.Ho = g.down ? (Hi - 2) / 2 + 1 : Hi << g.ups;
+    g.Wo = g.down ? (Wi - 2) / 2 + 1 : Wi << g.ups;
+    g.taps = ksize * ksize;
     g.M = (long long)B * g.Ho * g.Wo;
     return launch_conv(g, (hipStream_t)stream);
 }

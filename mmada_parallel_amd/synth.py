@@ -110,6 +110,9 @@ def synthetic_job(height: int = 512, width: int = 512, text_gen_length: int = 25
 # Defaults of VQGANDecoder.__init__ (MMaDA-Parallel-M/models/modeling_magvitv2.py:278-287); level 0 = full resolution.
 VQ_CFG_M = dict(ch=128, ch_mult=[1, 1, 2, 2, 4], num_res_blocks=[4, 4, 3, 4, 3], z_channels=13, out_ch=3)
 VQ_CFG_TINY = dict(ch=128, ch_mult=[1, 2], num_res_blocks=[1, 2], z_channels=13, out_ch=3)
+# Defaults of VQGANEncoder.__init__ (modeling_magvitv2.py:62-73)
+VQ_ENC_CFG_M = dict(ch=128, ch_mult=[1, 2, 2, 4, 4], num_res_blocks=[4, 3, 4, 3, 4], z_channels=13, in_ch=3)
+VQ_ENC_CFG_TINY = dict(ch=128, ch_mult=[1, 2], num_res_blocks=[2, 1], z_channels=13, in_ch=3)
 
 
 def vq_decoder_param_shapes(cfg: dict) -> Dict[str, tuple]:
@@ -150,13 +153,62 @@ def vq_decoder_param_shapes(cfg: dict) -> Dict[str, tuple]:
     return out
 
 
+def vq_encoder_param_shapes(cfg: dict) -> Dict[str, tuple]:
+    """State-dict keys and shapes of the reference VQGANEncoder (module tree modeling_magvitv2.py:81-141)."""
+    ch, mult, nrb, zc = cfg["ch"], cfg["ch_mult"], cfg["num_res_blocks"], cfg["z_channels"]
+    out: Dict[str, tuple] = {}
+
+    def conv(p, co, ci, k):
+        out[p + ".weight"], out[p + ".bias"] = (co, ci, k, k), (co,)
+
+    def norm(p, c):
+        out[p + ".weight"], out[p + ".bias"] = (c,), (c,)
+
+    def res(p, ci, co):
+        norm(p + ".norm1", ci); conv(p + ".conv1", co, ci, 3)
+        norm(p + ".norm2", co); conv(p + ".conv2", co, co, 3)
+        if ci != co:
+            conv(p + ".nin_shortcut", co, ci, 1)
+
+    conv("conv_in", ch, cfg["in_ch"], 3)
+    block_in = ch
+    for lvl in range(len(mult)):
+        block_out = ch * mult[lvl]
+        for b in range(nrb[lvl]):
+            res(f"down.{lvl}.block.{b}", block_in, block_out)
+            block_in = block_out
+        if lvl != len(mult) - 1:
+            conv(f"down.{lvl}.downsample.conv", block_in, block_in, 3)
+    res("mid.block_1", block_in, block_in)
+    norm("mid.attn_1.norm", block_in)
+    for n in ("q", "k", "v", "proj_out"):
+        conv("mid.attn_1." + n, block_in, block_in, 1)
+    res("mid.block_2", block_in, block_in)
+    norm("norm_out", block_in)
+    conv("conv_out", zc, block_in, 3)
+    conv("quant_conv", zc, zc, 1)
+    return out
+
+
+def synthetic_image(B: int, H: int, W: int, seed: int = 0) -> torch.Tensor:
+    """Seeded smooth-ish image batch in [-1, 1], [B, 3, H, W] fp32 (what image_transform_squash + Normalize(0.5, 0.5)
+    hands to get_code, MMaDA-Parallel-M/training/utils.py:208-213)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    low = torch.randn(B, 3, max(2, H // 8), max(2, W // 8), generator=g)
+    img = torch.nn.functional.interpolate(low, size=(H, W), mode="bilinear", align_corners=False)
+    img = img + 0.1 * torch.randn(B, 3, H, W, generator=g)
+    return torch.tanh(img)
+
+
 def synthetic_vq_state_dict(cfg: dict, seed: int = 0) -> Dict[str, torch.Tensor]:
-    """Seeded fp32 decoder weights (CPU generator, so every machine gets the same tensors): conv N(0, 1/fan_in),
+    """Seeded fp32 decoder (or, for a cfg with "in_ch", encoder) weights (CPU generator, so every machine gets the same tensors): conv N(0, 1/fan_in),
     conv bias N(0, 0.05²), GroupNorm weight 1+N(0, 0.1²), bias N(0, 0.1²)."""
     g = torch.Generator(device="cpu")
     g.manual_seed(seed)
     sd: Dict[str, torch.Tensor] = {}
-    for name, shape in vq_decoder_param_shapes(cfg).items():
+    shapes = vq_encoder_param_shapes(cfg) if "in_ch" in cfg else vq_decoder_param_shapes(cfg)
+    for name, shape in shapes.items():
         if len(shape) == 4:
             std = (shape[1] * shape[2] * shape[3]) ** -0.5
             sd[name] = torch.randn(shape, generator=g) * std

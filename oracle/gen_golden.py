@@ -17,6 +17,8 @@ Fixtures
   vq_decode.npz      MMaDA-Parallel-M MAGVITv2.decode_code (LFQuantizer.get_codebook_entry + VQGANDecoder, fp32) on
                      seeded synthetic decoder weights: a 2-level decoder (full output) and the default 5-level
                      decoder at 32x32 codes -> 512x512 (every 4th pixel) — models/modeling_magvitv2.py:208-221,277-433
+  vq_encode.npz      MAGVITv2.get_code (VQGANEncoder + LFQuantizer sign quantisation / get_indices) on seeded weights and
+                     a seeded synthetic image: indices + pre-quantisation z — models/modeling_magvitv2.py:62-171,201-206,422-427
 """
 from __future__ import annotations
 
@@ -344,6 +346,27 @@ def gen_vq_decode():
         out[name + "_stats"] = np.array([img.mean().item(), img.std().item(), img.abs().max().item()])
         print(f"vq_decode[{name}]: {tuple(idx.shape)} -> {tuple(img.shape)}, std {img.std().item():.4f}")
     np.savez_compressed(os.path.join(OUT, "vq_decode.npz"), **out)
+    # encoder direction: the reference's own MAGVITv2.get_code on its VQGANEncoder + LFQuantizer.forward / get_indices
+    out = {}
+    for name, cfg, B, res in (("tiny", synth.VQ_ENC_CFG_TINY, 2, 16), ("full", synth.VQ_ENC_CFG_M, 1, 512)):
+        seed = 17 if name == "tiny" else 18
+        sd = synth.synthetic_vq_state_dict(cfg, seed)
+        with contextlib.redirect_stdout(io.StringIO()):
+            enc = mv.VQGANEncoder(ch=cfg["ch"], ch_mult=cfg["ch_mult"], num_res_blocks=cfg["num_res_blocks"],
+                                  z_channels=cfg["z_channels"], in_ch=cfg["in_ch"])
+            quant = mv.LFQuantizer(codebook_dim=cfg["z_channels"])
+        enc.load_state_dict(sd, strict=True)
+        enc.eval()
+        img = synth.synthetic_image(B, res, res, seed=200 + seed)
+        with torch.no_grad():
+            idx = mv.MAGVITv2.get_code(SimpleNamespace(encoder=enc, quantize=quant), img)
+            z = enc(img)
+        out[name + "_seed"] = np.array(seed)
+        out[name + "_idx"] = idx.numpy()
+        out[name + "_z"] = z.numpy()
+        print(f"vq_encode[{name}]: {tuple(img.shape)} -> {tuple(idx.shape)}, z std {z.std().item():.3f}, "
+              f"|z| < 1e-3: {(z.abs() < 1e-3).sum().item()}")
+    np.savez_compressed(os.path.join(OUT, "vq_encode.npz"), **out)
     for k, v in saved.items():
         sys.modules.pop(k, None)
         if v is not None:

@@ -1,6 +1,8 @@
 """CPU ORACLE (test infrastructure — never imported by the product path).
 
-Plain-PyTorch fp32 restatement of the MAGVITv2 token -> pixel decode of MMaDA-Parallel-M:
+Plain-PyTorch fp32 restatement of the MAGVITv2 token <-> pixel paths of MMaDA-Parallel-M:
+    MAGVITv2.get_code                    /root/reference/MMaDA-Parallel-M/models/modeling_magvitv2.py:422-427
+    VQGANEncoder.forward                 modeling_magvitv2.py:143-171 (module tree :62-141), Downsample common_modules.py:83-90
     MAGVITv2.decode_code                 /root/reference/MMaDA-Parallel-M/models/modeling_magvitv2.py:429-433
     LFQuantizer.get_codebook_entry       modeling_magvitv2.py:208-221  (embedding table built at :187-195)
     VQGANDecoder.forward                 modeling_magvitv2.py:369-406  (module tree :277-367)
@@ -94,6 +96,37 @@ def decoder_forward(sd: Dict[str, torch.Tensor], cfg: dict, z: torch.Tensor, tap
 def decode_code(sd: Dict[str, torch.Tensor], cfg: dict, indices: torch.Tensor, shape=None) -> torch.Tensor:
     """MAGVITv2.decode_code (modeling_magvitv2.py:429-433): [B, N] int64 -> [B, 3, 16*h, 16*w] fp32."""
     return decoder_forward(sd, cfg, lfq_codebook_entry(indices, cfg.get("z_channels", 13), shape))
+
+
+@torch.no_grad()
+def encoder_forward(sd: Dict[str, torch.Tensor], cfg: dict, x: torch.Tensor) -> torch.Tensor:
+    """VQGANEncoder.forward (modeling_magvitv2.py:143-171): [B, 3, H, W] -> [B, z_channels, H/f, W/f]."""
+    n_levels = len(cfg["ch_mult"])
+    h = conv(x, sd, "conv_in", 1)
+    for lvl in range(n_levels):
+        for b in range(cfg["num_res_blocks"][lvl]):
+            h = resnet_block(h, sd, f"down.{lvl}.block.{b}")
+        if lvl != n_levels - 1:  # Downsample.forward, common_modules.py:83-90: pad right/bottom, 3x3 stride 2
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)
+            p = f"down.{lvl}.downsample.conv"
+            h = F.conv2d(h, sd[p + ".weight"], sd[p + ".bias"], stride=2, padding=0)
+    h = resnet_block(h, sd, "mid.block_1")
+    h = attn_block(h, sd, "mid.attn_1")
+    h = resnet_block(h, sd, "mid.block_2")
+    h = swish(group_norm(h, sd, "norm_out"))
+    h = conv(h, sd, "conv_out", 1)
+    return conv(h, sd, "quant_conv", 0)
+
+
+@torch.no_grad()
+def get_code(sd: Dict[str, torch.Tensor], cfg: dict, pixel_values: torch.Tensor, return_z: bool = False):
+    """MAGVITv2.get_code (modeling_magvitv2.py:422-427): sign quantisation (:241-243: z_q = +1 where z > 0 else -1) and
+    get_indices (:201-206: sum of 2^(dim-1-c) over the channels with z_q > 0) -> [B, N] int64."""
+    z = encoder_forward(sd, cfg, pixel_values)
+    dim = z.shape[1]
+    power = 2 ** torch.arange(dim - 1, -1, -1)
+    idx = (power.reshape(1, -1, 1, 1) * (z > 0).long()).sum(1).reshape(z.shape[0], -1)
+    return (idx, z) if return_z else idx
 
 
 def to_uint8_image(x: torch.Tensor) -> torch.Tensor:

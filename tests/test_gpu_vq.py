@@ -63,6 +63,22 @@ def test_conv2d_matches_torch_fp32(case):
     assert err <= 1e-5 * ref.abs().max().item() + 1e-6, f"max err {err:.3e} of range {ref.abs().max().item():.3f}"
 
 
+@pytest.mark.parametrize("H,W", [(16, 16), (10, 12), (9, 7)])
+def test_downsample_conv_matches_torch(H, W):
+    # Downsample.forward (common_modules.py:83-90): F.pad(x, (0,1,0,1)) then Conv2d(3, stride 2, padding 0)
+    g = torch.Generator().manual_seed(H * 31 + W)
+    x = torch.randn(2, 128, H, W, generator=g)
+    w = torch.randn(128, 128, 3, 3, generator=g) * 0.03
+    b = torch.randn(128, generator=g)
+    ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w, b, stride=2, padding=0)
+    Ho, Wo = ref.shape[2:]
+    xd, wd, bd = nhwc(x).to(DEV), w.permute(0, 2, 3, 1).contiguous().to(DEV), b.to(DEV)
+    out = torch.empty((2, Ho, Wo, 128), dtype=torch.float32, device=DEV)
+    abi.check(abi.lib().mmada_vq_conv2d(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), 0, out.data_ptr(), 2, H, W, 128, 128,
+                                        3, -1, abi.stream_ptr()), "conv2d")
+    assert (out.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+
+
 def test_conv2d_residual_may_alias_output():
     # ResnetBlock without nin_shortcut: x = x + conv2(h) is done in place on x
     g = torch.Generator().manual_seed(3)
@@ -155,3 +171,48 @@ def test_vq_bind_errors_are_loud():
     vq = MAGVITv2.from_state_dict(sd, cfg, device=DEV)
     with pytest.raises(abi.MmadaError):
         vq.decode_code(torch.zeros((1, 9), dtype=torch.long))  # 3x3 grid: not a multiple of 32 positions
+
+
+@pytest.mark.parametrize("name", ["tiny", "full"])
+def test_get_code_matches_reference_fixture_and_oracle(name):
+    z = np.load(os.path.join(GOLDEN, "vq_encode.npz"))
+    cfg = synth.VQ_ENC_CFG_TINY if name == "tiny" else synth.VQ_ENC_CFG_M
+    seed = int(z[name + "_seed"])
+    sd = synth.synthetic_vq_state_dict(cfg, seed)
+    B, res = (2, 16) if name == "tiny" else (1, 512)
+    img = synth.synthetic_image(B, res, res, seed=200 + seed)
+    vq = MAGVITv2.from_state_dict({"encoder." + k: v for k, v in sd.items()}, cfg, device=DEV)
+    idx, zz = vq.get_code(img.to(DEV), return_z=True)
+    idx, zz = idx.cpu(), zz.cpu()
+    zref = torch.from_numpy(z[name + "_z"])
+    err = (zz - zref).abs().max().item()
+    print(f"vq encode [{name}] z vs reference fixture: max err {err:.3e} (range {zref.abs().max().item():.3f})")
+    assert err <= 2e-5 * zref.abs().max().item()
+    # indices are the signs of z: bit-exact wherever no |z| is within the fp32 tolerance of zero
+    iref = torch.from_numpy(z[name + "_idx"])
+    sure = (zref.abs() > 1e-4).all(1).reshape(B, -1)
+    assert sure.float().mean().item() > 0.95
+    assert torch.equal(idx[sure], iref[sure])
+    # and they are exactly the bit pattern of OUR z everywhere (LFQuantizer.get_indices)
+    power = 2 ** torch.arange(cfg["z_channels"] - 1, -1, -1)
+    mine = (power.reshape(1, -1, 1, 1) * (zz > 0).long()).sum(1).reshape(B, -1)
+    assert torch.equal(idx, mine)
+    # oracle evaluated on this machine
+    oi, oz = vq_oracle.get_code(sd, cfg, img, return_z=True)
+    assert (zz - oz).abs().max().item() <= 2e-5 * oz.abs().max().item()
+    zq, idx2 = vq.encode(img.to(DEV))
+    assert torch.equal(idx2.cpu(), idx) and torch.equal(zq.cpu(), torch.where(zz > 0, 1.0, -1.0))
+
+
+def test_encode_decode_roundtrip_runs_on_one_model():
+    """A full MAGVITv2 checkpoint layout (encoder.* + decoder.* + quantize.* buffers) builds both directions."""
+    enc, dec = synth.VQ_ENC_CFG_TINY, synth.VQ_CFG_TINY
+    sd = {"encoder." + k: v for k, v in synth.synthetic_vq_state_dict(enc, 3).items()}
+    sd.update({"decoder." + k: v for k, v in synth.synthetic_vq_state_dict(dec, 4).items()})
+    sd["quantize.embedding"] = torch.zeros(8192, 13)  # buffer of the reference checkpoint: ignored
+    vq = MAGVITv2(sd, dec, device=DEV, encoder_config=enc)
+    img = synth.synthetic_image(1, 64, 32, seed=9).to(DEV)
+    idx = vq.get_code(img)
+    assert idx.shape == (1, 32 * 16) and idx.min().item() >= 0 and idx.max().item() < 8192
+    out = vq.decode_code(idx, shape=(32, 16))
+    assert out.shape == (1, 3, 64, 32) and torch.isfinite(out).all()

@@ -235,3 +235,24 @@ def test_lfq_codebook_entry_is_the_bit_pattern():
     assert z[0, :, 0, 1].tolist() == [-1.0] * 12 + [1.0]
     assert z[0, :, 1, 0].tolist() == [1.0] + [-1.0] * 12
     assert z[0, :, 1, 1].tolist() == [1.0] * 13
+
+
+@pytest.mark.parametrize("name", ["tiny", "full"])
+def test_vq_get_code_oracle_matches_reference(name):
+    """Encoder direction: oracle get_code vs the reference's MAGVITv2.get_code (VQGANEncoder + LFQuantizer).  The
+    indices are signs of z: they must agree wherever |z| is not within fp32 noise of zero."""
+    from oracle import vq_oracle
+
+    z = np.load(os.path.join(GOLDEN, "vq_encode.npz"))
+    cfg = synth.VQ_ENC_CFG_TINY if name == "tiny" else synth.VQ_ENC_CFG_M
+    seed = int(z[name + "_seed"])
+    sd = synth.synthetic_vq_state_dict(cfg, seed)
+    B, res = (2, 16) if name == "tiny" else (1, 512)
+    img = synth.synthetic_image(B, res, res, seed=200 + seed)
+    idx, zz = vq_oracle.get_code(sd, cfg, img, return_z=True)
+    zref = torch.from_numpy(z[name + "_z"])
+    assert (zz - zref).abs().max().item() <= 2e-5 * zref.abs().max().item()
+    iref = torch.from_numpy(z[name + "_idx"])
+    sure = (zref.abs() > 1e-4).all(1).reshape(B, -1)  # positions whose 13 signs are all unambiguous
+    assert sure.float().mean().item() > 0.95
+    assert torch.equal(idx[sure], iref[sure])
