@@ -178,6 +178,14 @@ int mmada_image_commit_m(mmada_handle* h, int64_t* ids, int B, int L, const int3
                          const int32_t* sampled_in, const void* p_in, const void* gumbel, float remask_temp,
                          const int32_t* mask_len_sched, int text_vocab_size, void* stream);
 
+/* (A, text-to-image) re-mask + write-back of generate_image (generators/image_generation_generator.py:99-103,178-207,
+ * utils/generation_utils.py:47-64): as mmada_image_commit_m, but the number of tokens that stay masked is
+ * keep_n[0].clamp(0, unknown-1) with no floor of 1 (keep_n = 0 on the last step masks nothing).  pos_map lists the
+ * image slots (positions masked in the prompt); already-known slots keep their ids. */
+int mmada_image_commit_g(mmada_handle* h, int64_t* ids, int B, int L, const int32_t* pos_map, int N,
+                         const int32_t* sampled_in, const void* p_in, const void* gumbel, float remask_temp,
+                         const int32_t* keep_n, int text_vocab_size, void* stream);
+
 /* (M variant) LFQ codebook gather, MMaDA-Parallel-M/models/modeling_magvitv2.py:186-194,208-221:
  * out[b, c, n] = 2·bit_c(idx[b,n]) − 1 as bf16/f32, c in [0,nbits) with bit 0 = most significant
  * (mask = 2^(nbits-1-c)).  idx: device int64 [B,N]; out: device [B,nbits,N] (dtype_f32 ? float : bf16). */

@@ -6,6 +6,7 @@ Public surface mirrors the reference (tyfeld/MMaDA-Parallel, MMaDA-Parallel-A):
 from .model import LLaDAForMultiModalGeneration, LLaDAConfigLite  # noqa: F401
 from .generators.parallel_generator import generate_ti2ti, generate_ti2ti_stepwise, cosine_schedule  # noqa: F401
 from .generators.interleave_generator import interleave_generate  # noqa: F401
+from .generators.image_generation_generator import generate_image  # noqa: F401
 from .vq import MAGVITv2  # noqa: F401
 
-__all__ = ["LLaDAForMultiModalGeneration", "LLaDAConfigLite", "generate_ti2ti", "generate_ti2ti_stepwise", "interleave_generate", "cosine_schedule", "MAGVITv2"]
+__all__ = ["LLaDAForMultiModalGeneration", "LLaDAConfigLite", "generate_ti2ti", "generate_ti2ti_stepwise", "interleave_generate", "cosine_schedule", "MAGVITv2", "generate_image"]

@@ -59,6 +59,8 @@ SIGNATURES = {
                                     c_void_p, c_void_p]),
     "mmada_image_commit_m": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
                                      c_float, c_void_p, c_int, c_void_p]),
+    "mmada_image_commit_g": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,
+                                     c_float, c_void_p, c_int, c_void_p]),
     "mmada_lfq_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mmada_profile_begin": (c_int, [c_void_p, c_int]),
     "mmada_profile_end": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -445,6 +445,15 @@ int mmada_image_commit_m(mmada_handle* h, int64_t* ids, int B, int L, const int3
                                mask_len_sched, h->cfg.mask_token_id, text_vocab_size, 0, 1, (hipStream_t)stream);
 }
 
+int mmada_image_commit_g(mmada_handle* h, int64_t* ids, int B, int L, const int32_t* pos_map, int N,
+                         const int32_t* sampled_in, const void* p_in, const void* gumbel, float remask_temp,
+                         const int32_t* keep_n, int text_vocab_size, void* stream) {
+    if (!h || !ids || !pos_map || !sampled_in || !p_in || !gumbel || !keep_n)
+        return mm_fail("mmada_image_commit_g: null argument");
+    return launch_image_commit(ids, B, L, pos_map, N, sampled_in, (const bf16_t*)p_in, (const bf16_t*)gumbel, remask_temp,
+                               keep_n, h->cfg.mask_token_id, text_vocab_size, 0, 2, (hipStream_t)stream);
+}
+
 int mmada_image_probs(mmada_handle* h, const void* cond, const void* unc_text, const void* unc_img, int B, int N, int CB,
                       float cfg_scale, float cfg_img, void* probs_out, int32_t* argmax_out, void* pmax_out,
                       void* stream) {

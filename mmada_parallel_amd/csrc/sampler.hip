@@ -272,7 +272,7 @@ __global__ __launch_bounds__(1024) void image_commit_kernel(int64_t* __restrict_
                                                             const bf16_t* __restrict__ p_in,
                                                             const bf16_t* __restrict__ noise, float remask_temp,
                                                             const int32_t* __restrict__ mask_len_sched, int mask_id,
-                                                            int text_vocab, int codebook) {
+                                                            int text_vocab, int codebook, int keep_rule) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* conf = (float*)smem;          // [N] bf16-valued
     int* samp = (int*)(conf + N);        // [N]
@@ -308,8 +308,10 @@ __global__ __launch_bounds__(1024) void image_commit_kernel(int64_t* __restrict_
     if (my_unknown) atomicAdd(&s_unknown, my_unknown);
     __syncthreads();
     // mask_len = max(1, min(unknown-1, floor(N*ratio))) (:318-324), then clamp(…, 0, N-1) (:43)
+    // keep_rule (generate_image, generators/image_generation_generator.py:99-103 + utils/generation_utils.py:62):
+    // k = keep_n.clamp(0, unknown-1) with keep_n supplied as is (0 on the last step) — no floor of 1
     int k = min(s_unknown - 1, mask_len_sched[0]);
-    k = max(1, k);
+    k = keep_rule ? max(0, k) : max(1, k);
     k = max(0, min(k, N - 1));
     for (int n = tid; n < N; n += blockDim.x) {
         const float c = conf[n];
@@ -380,10 +382,10 @@ int launch_image_commit(int64_t* ids, int B, int L, const int32_t* pos_map, int 
     if (mvar) {
         if (!noise) return mm_fail("image_commit (M variant): the gumbel tensor is required");
         hipLaunchKernelGGL(image_commit_kernel<true>, dim3(B), dim3(1024), (size_t)N * 8, s, ids, L, pos_map, N, sampled_in,
-                           p_in, noise, remask_temp, mask_len_sched, mask_id, text_vocab, codebook);
+                           p_in, noise, remask_temp, mask_len_sched, mask_id, text_vocab, codebook, mvar == 2);
     } else
         hipLaunchKernelGGL(image_commit_kernel<false>, dim3(B), dim3(1024), (size_t)N * 8, s, ids, L, pos_map, N, sampled_in,
-                           p_in, noise, remask_temp, mask_len_sched, mask_id, text_vocab, codebook);
+                           p_in, noise, remask_temp, mask_len_sched, mask_id, text_vocab, codebook, 0);
     MM_CHECK_HIP(hipGetLastError());
     return 0;
 }

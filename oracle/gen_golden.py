@@ -14,6 +14,8 @@ Fixtures
                      sampler passes to every model call + final outputs — generators/parallel_generator.py:102-368
   e2e_tiny.npz       generate_ti2ti with the real tiny model at temperature 0: ids at every model call + outputs
   logconf_table.npy  torch.log(p + 1e-10) in bf16 for every non-negative bf16 p (parallel_generator.py:36)
+  t2i_traj.npz       generate_image (A text-to-image MaskGIT sampler) driven by the same kind of stub model, with and
+                     without CFG, temperature 0 and 1 (seeded CPU generator) — generators/image_generation_generator.py
   vq_decode.npz      MMaDA-Parallel-M MAGVITv2.decode_code (LFQuantizer.get_codebook_entry + VQGANDecoder, fp32) on
                      seeded synthetic decoder weights: a 2-level decoder (full output) and the default 5-level
                      decoder at 32x32 codes -> 512x512 (every 4th pixel) — models/modeling_magvitv2.py:208-221,277-433
@@ -375,6 +377,48 @@ def gen_vq_decode():
         sys.modules.pop(k, None)
 
 
+def gen_t2i_traj():
+    """Reference generate_image (generators/image_generation_generator.py) driven by a stub model that returns seeded
+    random bf16 logits: ids of every model call + returned vq ids.  temperature > 0 draws from a seeded CPU generator."""
+    from generators.image_generation_generator import generate_image
+    from tests.helpers import T2I_CASES, t2i_job
+
+    class Stub(torch.nn.Module):
+        def __init__(self, seed, V):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+            self.seed, self.V, self.n, self.calls = seed, V, 0, []
+            self.module = self  # the reference calls model.module.caching() on anything that is not its own class
+
+        def caching(self, enable=True):
+            pass
+
+        def forward(self, ids, infer=True, use_cache=False):
+            self.n += 1
+            self.calls.append(ids.clone())
+            return SimpleNamespace(logits=stub_logits(self.seed, self.n, 1, ids.shape[1], self.V))
+
+    job = t2i_job()
+    V = STUB_TEXT_VOCAB + STUB_CB
+    out = {}
+    for ci, (name, kw) in enumerate(T2I_CASES.items()):
+        seed = 71 + ci
+        stub = Stub(seed, V)
+        gen = torch.Generator().manual_seed(900 + ci) if kw["temperature"] > 0 else None
+        with contextlib.redirect_stdout(io.StringIO()):
+            vq = generate_image(stub, job["prompt"], seq_len=job["seq_len"], newline_every=job["newline_every"],
+                                uncon_ids=job["uncon_ids"], code_start=job["code_start"], codebook_size=STUB_CB,
+                                text_vocab_size=STUB_TEXT_VOCAB, generator=gen, debug=False, **kw)
+        L = job["prompt"].shape[1]
+        out[name + "_calls_len"] = np.array([c.shape[1] for c in stub.calls])
+        out[name + "_calls"] = torch.cat([torch.nn.functional.pad(c, (0, L + 8 - c.shape[1]), value=-1) for c in stub.calls], 0).numpy()
+        out[name + "_vq"] = vq.numpy()
+        out[name + "_seed"] = np.array(seed)
+        out[name + "_gen_seed"] = np.array(900 + ci)
+        print(f"t2i_traj[{name}]: {len(stub.calls)} model calls, vq {tuple(vq.shape)}")
+    np.savez_compressed(os.path.join(OUT, "t2i_traj.npz"), **out)
+
+
 def gen_tables():
     b = torch.arange(0, 0x7f80, dtype=torch.int32).to(torch.int16)
     np.save(os.path.join(OUT, "logconf_table.npy"), torch.log(b.view(torch.bfloat16) + 1e-10).view(torch.int16).numpy())
@@ -390,6 +434,7 @@ if __name__ == "__main__":
             globals()[fn]()
         sys.exit(0)
     gen_tables()
+    gen_t2i_traj()
     gen_vq_decode()
     gen_stepwise_traj()
     gen_m_traj()

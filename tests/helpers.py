@@ -55,3 +55,30 @@ M_CASES = {
 M_SHAPE = dict(prompt=6, N=16, T=16, text_vocab=2048, CB=512, soi=2040, eoi=2041, bos=2042, mask_id=126336)
 
 STEPWISE_CASES = {"sw_img4": dict(text_steps=10, cfg_scale=0.0, cfg_img=4.0), "sw_both": dict(text_steps=14, cfg_scale=2.5, cfg_img=4.0)}
+
+
+# generate_image (A, text-to-image) stub-logit cases: tests/golden/t2i_traj.npz
+T2I_CASES = {
+    "g_nocfg_t0": dict(timesteps=6, temperature=0.0, cfg_scale=0.0),
+    "g_cfg_t0": dict(timesteps=5, temperature=0.0, cfg_scale=3.0),
+    "g_cfg_t1": dict(timesteps=4, temperature=1.0, cfg_scale=2.0),
+}
+
+
+def t2i_job(seed=3, P=8, U=4, side=4):
+    """prompt = [P text tokens][2 tokens][side rows of (side masks + newline)][2 tokens]; code_start = P + 2."""
+    g = torch.Generator().manual_seed(seed)
+    text = torch.randint(0, 1000, (P,), generator=g).tolist()
+    body = []
+    for _ in range(side):
+        body += [synth.MASK] * side + [synth.NEW_LINE]
+    prompt = torch.tensor([text + [synth.BOA, synth.BOI] + body + [synth.EOI, synth.EOA]], dtype=torch.long)
+    uncon = torch.randint(0, 1000, (1, U), generator=g)
+    return dict(prompt=prompt, uncon_ids=uncon, code_start=P + 2, seq_len=side * side, newline_every=side)
+
+
+class ReplayRng:
+    """Replays the reference's torch.rand(shape, dtype=bf16, generator=cpu_generator) draws on the CPU generator."""
+
+    def rand(self, shape, dtype, device, generator):
+        return torch.rand(tuple(shape), dtype=dtype, generator=generator).to(device)

@@ -482,3 +482,44 @@ def test_stepwise_generator_bit_exact(tiny_model, name):
             assert sampled.shape == (1, job["seq_len"]) and int(sampled.min()) >= 0 and int(sampled.max()) < STUB_CB
     assert torch.equal(torch.cat(stub.calls, 0), torch.from_numpy(z[name + "_calls"]))
     assert shown == z[name + "_yields"].tolist()   # the reference's display cadence
+
+
+# ------------------------------------------------------------------- generate_image (A text-to-image MaskGIT sampler)
+from helpers import T2I_CASES, ReplayRng, t2i_job  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(T2I_CASES))
+def test_generate_image_stub_trajectory_bit_exact(tiny_model, name):
+    """generate_image on stub logits: the ids of EVERY model call (cond and, with CFG, the shorter/longer uncond
+    sequence) and the returned vq ids equal the reference's own generate_image (tests/golden/t2i_traj.npz); at
+    temperature 1 the reference's bf16 uniform draws are replayed from the same seeded CPU generator."""
+    from mmada_parallel_amd.generators.image_generation_generator import generate_image
+
+    z = np.load(os.path.join(GOLDEN, "t2i_traj.npz"))
+    job, kw = t2i_job(), T2I_CASES[name]
+    V = STUB_TEXT_VOCAB + STUB_CB
+    stub = _stubbed(tiny_model, int(z[name + "_seed"]), V)
+    gen = torch.Generator().manual_seed(int(z[name + "_gen_seed"])) if kw["temperature"] > 0 else None
+    vq = generate_image(stub, job["prompt"], seq_len=job["seq_len"], newline_every=job["newline_every"],
+                        uncon_ids=job["uncon_ids"], code_start=job["code_start"], codebook_size=STUB_CB,
+                        text_vocab_size=STUB_TEXT_VOCAB, generator=gen, rng=ReplayRng(), **kw)
+    lens = z[name + "_calls_len"]
+    assert len(stub.calls) == len(lens)
+    for i, n in enumerate(lens):
+        ref = torch.from_numpy(z[name + "_calls"][i, :n]).view(1, -1)
+        assert torch.equal(stub.calls[i], ref), f"model call {i} differs"
+    assert torch.equal(vq.cpu(), torch.from_numpy(z[name + "_vq"]))
+
+
+def test_generate_image_real_tiny_model_runs_and_is_deterministic(tiny_model):
+    from mmada_parallel_amd import generate_image
+
+    job = t2i_job(side=8)
+    kw = dict(seq_len=job["seq_len"], newline_every=job["newline_every"], uncon_ids=job["uncon_ids"],
+              code_start=job["code_start"], timesteps=5, temperature=0.0, cfg_scale=2.0)
+    a = generate_image(tiny_model, job["prompt"], **kw)
+    b = generate_image(tiny_model, job["prompt"], **kw)
+    assert a.shape == (1, 64) and torch.equal(a, b)
+    assert int(a.min()) >= synth.TEXT_VOCAB and int(a.max()) < synth.TEXT_VOCAB + synth.CODEBOOK  # every slot was filled
+    with pytest.raises(TypeError):
+        generate_image(object(), job["prompt"], **kw)

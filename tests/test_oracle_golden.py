@@ -256,3 +256,37 @@ def test_vq_get_code_oracle_matches_reference(name):
     sure = (zref.abs() > 1e-4).all(1).reshape(B, -1)  # positions whose 13 signs are all unambiguous
     assert sure.float().mean().item() > 0.95
     assert torch.equal(idx[sure], iref[sure])
+
+
+# ---- generate_image (A text-to-image MaskGIT sampler, generators/image_generation_generator.py:14-251) ----------------
+from helpers import T2I_CASES, t2i_job  # noqa: E402
+
+
+def _t2i_calls(z, name):
+    lens = z[name + "_calls_len"]
+    return [torch.from_numpy(z[name + "_calls"][i, :n]).view(1, -1) for i, n in enumerate(lens)]
+
+
+@pytest.mark.parametrize("name", list(T2I_CASES))
+def test_t2i_trajectory_matches_reference(name):
+    from oracle import generate_image_oracle
+
+    z = np.load(os.path.join(GOLDEN, "t2i_traj.npz"))
+    seed, job, kw = int(z[name + "_seed"]), t2i_job(), T2I_CASES[name]
+    V = STUB_TEXT_VOCAB + STUB_CB
+    n = [0]
+
+    def model_fn(ids):
+        n[0] += 1
+        return stub_logits(seed, n[0], 1, ids.shape[1], V)
+
+    gen = torch.Generator().manual_seed(int(z[name + "_gen_seed"])) if kw["temperature"] > 0 else None
+    trace = []
+    vq = generate_image_oracle.generate(model_fn, job["prompt"], job["seq_len"], kw["timesteps"], kw["temperature"],
+                                        kw["cfg_scale"], job["uncon_ids"], job["code_start"], STUB_CB, STUB_TEXT_VOCAB,
+                                        generator=gen, trace=trace)
+    ref = _t2i_calls(z, name)
+    assert len(trace) == len(ref)
+    for i, (a, b) in enumerate(zip(trace, ref)):
+        assert torch.equal(a, b), f"model call {i} differs"
+    assert torch.equal(vq, torch.from_numpy(z[name + "_vq"]))
