@@ -46,6 +46,9 @@ class TorchRng:
         noise = torch.rand_like(l64, dtype=torch.float64)
         return torch.argmax(l64.exp() / ((-torch.log(noise)) ** temperature), dim=-1)
 
+    def rand_f64(self, shape, device) -> torch.Tensor:
+        return torch.rand(tuple(shape), dtype=torch.float64, device=device)  # torch.rand_like(logits, dtype=float64)
+
     def multinomial(self, probs2d: torch.Tensor, generator) -> torch.Tensor:
         return torch.multinomial(probs2d, 1, generator=generator)[:, 0]  # :220-222
 

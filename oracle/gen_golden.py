@@ -16,6 +16,10 @@ Fixtures
   logconf_table.npy  torch.log(p + 1e-10) in bf16 for every non-negative bf16 p (parallel_generator.py:36)
   t2i_traj.npz       generate_image (A text-to-image MaskGIT sampler) driven by the same kind of stub model, with and
                      without CFG, temperature 0 and 1 (seeded CPU generator) — generators/image_generation_generator.py
+  mmu_traj.npz       MMaDA-Parallel-M MMadaModelLM.mmu_generate (block-wise text sampler) on stub logits, B = 2, with
+                     and without CFG, temperature 0 and 0.6 — models/modeling_mmada.py:618-692
+  m_t2i_traj.npz     MMaDA-Parallel-M MMadaModelLM.t2i_generate (MaskGIT text-to-image) on stub logits with replayed
+                     multinomial / uniform draws, with and without guidance — models/modeling_mmada.py:264-359
   vq_decode.npz      MMaDA-Parallel-M MAGVITv2.decode_code (LFQuantizer.get_codebook_entry + VQGANDecoder, fp32) on
                      seeded synthetic decoder weights: a 2-level decoder (full output) and the default 5-level
                      decoder at 32x32 codes -> 512x512 (every 4th pixel) — models/modeling_magvitv2.py:208-221,277-433
@@ -377,6 +381,117 @@ def gen_vq_decode():
         sys.modules.pop(k, None)
 
 
+def gen_mmu_traj():
+    """Reference MMadaModelLM.mmu_generate (models/modeling_mmada.py:618-692) on stub logits (B = 2); temperature > 0
+    draws (torch.rand_like, float64) come from per-call seeded generators (SeededRng), replayed by the tests."""
+    import importlib
+    import types
+    from unittest import mock
+
+    from oracle.interleave_oracle import SeededRng
+    from tests.helpers import MMU_CASES, MMU_SHAPE
+
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [M_REF + "/models"]
+    saved = sys.modules.get("models")
+    sys.modules["models"] = pkg
+    mm = importlib.import_module("models.modeling_mmada")
+    sh = MMU_SHAPE
+    out = {}
+    for ci, (name, kw) in enumerate(MMU_CASES.items()):
+        seed = 91 + ci
+        g = torch.Generator().manual_seed(seed)
+        idx = torch.randint(0, 2000, (sh["B"], sh["P"]), generator=g)
+        calls, n = [], [0]
+
+        class FakeSelf:
+            device = torch.device("cpu")
+
+            def __call__(self, ids, attention_bias=None):
+                n[0] += 1
+                calls.append(ids.clone())
+                return SimpleNamespace(logits=stub_logits(seed, n[0], ids.shape[0], ids.shape[1], sh["V"]))
+
+        rng = SeededRng(seed)
+
+        def fake_rand_like(t, dtype=None, **_):
+            return rng.rand_f64(t.shape)
+
+        with mock.patch.object(torch, "rand_like", fake_rand_like):
+            x = mm.MMadaModelLM.mmu_generate(FakeSelf(), idx=idx, mask_id=sh["mask_id"], **kw)
+        out[name + "_idx"] = idx.numpy()
+        out[name + "_calls"] = torch.stack(calls, 0).numpy()
+        out[name + "_x"] = x.numpy()
+        out[name + "_seed"] = np.array(seed)
+        print(f"mmu_traj[{name}]: {len(calls)} forwards of shape {tuple(calls[0].shape)}")
+    np.savez_compressed(os.path.join(OUT, "mmu_traj.npz"), **out)
+    sys.modules.pop("models", None)
+    if saved is not None:
+        sys.modules["models"] = saved
+
+
+def gen_m_t2i_traj():
+    """Reference MMadaModelLM.t2i_generate (models/modeling_mmada.py:264-359) on stub logits; torch.multinomial and
+    Tensor.uniform_ are served by per-call seeded generators (SeededRng) that the tests replay."""
+    import importlib
+    import types
+    from unittest import mock
+
+    from oracle.interleave_oracle import SeededRng
+    from tests.helpers import M_T2I_CASES, M_T2I_SHAPE, m_t2i_job
+
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [M_REF + "/models"]
+    saved = sys.modules.get("models")
+    sys.modules["models"] = pkg
+    mm = importlib.import_module("models.modeling_mmada")
+    sh = M_T2I_SHAPE
+    V = sh["text_vocab"] + sh["CB"]
+    out = {}
+    for ci, (name, kw) in enumerate(M_T2I_CASES.items()):
+        seed = 111 + ci
+        inp, unc = m_t2i_job(seed, kw["B"], kw["known"])
+        calls, n = [], [0]
+
+        class FakeSelf:
+            def __call__(self, ids, attention_bias=None):
+                n[0] += 1
+                calls.append(ids.clone())
+                return SimpleNamespace(logits=stub_logits(seed, n[0], ids.shape[0], ids.shape[1], V))
+
+        class Tok:
+            def __len__(self):
+                return sh["text_vocab"]
+
+        rng = SeededRng(seed)
+        real_uniform = torch.Tensor.uniform_
+
+        def fake_multinomial(inp_, num, replacement=False, *, generator=None):
+            return rng.multinomial(inp_)[:, None]
+
+        def fake_uniform(self, a=0, b=1, *, generator=None):
+            return real_uniform(self, a, b, generator=rng._g())
+
+        ones = torch.ones_like(inp)
+        work = inp.clone()
+        with mock.patch.object(torch, "multinomial", fake_multinomial), \
+                mock.patch.object(torch.Tensor, "uniform_", fake_uniform):
+            ids = mm.MMadaModelLM.t2i_generate(
+                FakeSelf(), input_ids=work, uncond_input_ids=unc.clone() if kw["uncond"] else None, attention_mask=ones,
+                uncond_attention_mask=ones, temperature=kw["temperature"], timesteps=kw["timesteps"],
+                guidance_scale=kw["guidance_scale"], seq_len=sh["N"], mask_token_id=sh["mask_id"],
+                resolution=sh["resolution"], codebook_size=sh["CB"], uni_prompting=SimpleNamespace(text_tokenizer=Tok()))
+        out[name + "_calls"] = torch.stack(calls, 0).numpy()
+        out[name + "_ids"] = ids.numpy()
+        out[name + "_final_input"] = work.numpy()
+        out[name + "_seed"] = np.array(seed)
+        print(f"m_t2i_traj[{name}]: {len(calls)} forwards of shape {tuple(calls[0].shape)}")
+    np.savez_compressed(os.path.join(OUT, "m_t2i_traj.npz"), **out)
+    sys.modules.pop("models", None)
+    if saved is not None:
+        sys.modules["models"] = saved
+
+
 def gen_t2i_traj():
     """Reference generate_image (generators/image_generation_generator.py) driven by a stub model that returns seeded
     random bf16 logits: ids of every model call + returned vq ids.  temperature > 0 draws from a seeded CPU generator."""
@@ -435,6 +550,8 @@ if __name__ == "__main__":
         sys.exit(0)
     gen_tables()
     gen_t2i_traj()
+    gen_mmu_traj()
+    gen_m_t2i_traj()
     gen_vq_decode()
     gen_stepwise_traj()
     gen_m_traj()

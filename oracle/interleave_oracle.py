@@ -98,3 +98,98 @@ def generate(model_fn: Callable, input_ids: torch.Tensor, uncond_input_ids: torc
             ids = so.image_commit_m(ids, pos, sampled_ids.to(torch.int32), p_sel, gumbel, temperature, mlen, mask_id,
                                     text_vocab)
     return sampled_ids, ids[:, ts:]
+
+
+def mmu_generate(model_fn: Callable, idx: torch.Tensor, max_new_tokens: int, steps: int, block_length: int,
+                 temperature: float, cfg_scale: float, mask_id: int, rng=None, trace: Optional[list] = None,
+                 eot_token=None, stop_on_eot: bool = False):
+    """MMadaModelLM.mmu_generate / mmu_generate_fast (modeling_mmada.py:618-766), plain torch CPU ops in the reference's
+    dtypes (bf16 CFG combine, float64 softmax / Gumbel-max, per-row topk).  Pinned by tests/golden/mmu_traj.npz."""
+    import torch.nn.functional as F
+
+    B, P = idx.shape
+    x = torch.full((B, P + max_new_tokens), mask_id, dtype=torch.long)
+    x[:, :P] = idx.clone()
+    prompt_index = x != mask_id
+    num_blocks = max_new_tokens // block_length
+    steps = steps // num_blocks
+    for nb in range(num_blocks):
+        blk = x[:, P + nb * block_length:P + (nb + 1) * block_length] == mask_id
+        ntt = [get_num_transfer_tokens(int(blk[j].sum()), steps) for j in range(B)]  # :63-81 per row
+        for i in range(steps):
+            mask_index = x == mask_id
+            if cfg_scale > 0.0:  # :660-666
+                un_x = x.clone()
+                un_x[prompt_index] = mask_id
+                both = torch.cat([x, un_x], dim=0)
+                if trace is not None:
+                    trace.append(both.clone())
+                logits = model_fn(both)
+                logits, un_logits = torch.chunk(logits, 2, dim=0)
+                logits = un_logits + (cfg_scale + 1) * (logits - un_logits)
+            else:
+                if trace is not None:
+                    trace.append(x.clone())
+                logits = model_fn(x)
+            if temperature == 0:  # add_gumbel_noise :49-60 + argmax
+                x0 = torch.argmax(logits, dim=-1)
+            else:
+                x0 = rng.text_gumbel_argmax(logits, temperature)
+            p = F.softmax(logits.to(torch.float64), dim=-1)
+            x0_p = torch.squeeze(torch.gather(p, dim=-1, index=torch.unsqueeze(x0, -1)), -1)
+            x0_p[:, P + (nb + 1) * block_length:] = -float("inf")  # :677
+            x0 = torch.where(mask_index, x0, x)
+            confidence = torch.where(mask_index, x0_p, -float("inf"))
+            transfer = torch.zeros_like(x0, dtype=torch.bool)
+            for j in range(B):
+                _, sel = torch.topk(confidence[j], k=ntt[j][i])
+                transfer[j, sel] = True
+            x[transfer] = x0[transfer]
+        if stop_on_eot and eot_token is not None:  # :756-761
+            last = P + (nb + 1) * block_length - 1
+            if last < x.shape[1] and bool(torch.all(x[:, last] == eot_token)):
+                break
+    return x
+
+
+def t2i_generate(model_fn: Callable, input_ids: torch.Tensor, uncond_input_ids: Optional[torch.Tensor], temperature: float,
+                 timesteps: int, guidance_scale: float, seq_len: int, mask_token_id: int, resolution: int, codebook_size: int,
+                 tok_len: int, rng, generator=None, trace: Optional[list] = None):
+    """MMadaModelLM.t2i_generate (modeling_mmada.py:264-359) + sampling.mask_by_random_topk (sampling.py:31-36), plain
+    torch CPU ops in the reference's dtypes.  Pinned by tests/golden/m_t2i_traj.npz.  Mutates input_ids like the reference."""
+    N = seq_len
+    cur = input_ids[:, -(N + 1):-1].clone()
+    cur = torch.where(cur == mask_token_id, mask_token_id, cur - tok_len)
+    if uncond_input_ids is not None:
+        uncond_prefix = uncond_input_ids[:, :resolution + 1]
+    sampled_ids = None
+    for step in range(timesteps):
+        if uncond_input_ids is not None and guidance_scale > 0:
+            uncond_input_ids = torch.cat([uncond_prefix, input_ids[:, resolution + 1:]], dim=1)
+            model_input = torch.cat([input_ids, uncond_input_ids])
+            if trace is not None:
+                trace.append(model_input.clone())
+            cond_logits, uncond_logits = torch.chunk(model_fn(model_input), 2, dim=0)
+            logits = (1 + guidance_scale) * cond_logits - guidance_scale * uncond_logits
+        else:
+            if trace is not None:
+                trace.append(input_ids.clone())
+            logits = model_fn(input_ids)
+        logits = logits[:, -(N + 1):-1, tok_len:tok_len + codebook_size]
+        probs = logits.softmax(dim=-1)
+        sampled_ids = rng.multinomial(probs.reshape(-1, logits.size(-1)), generator).view(*logits.shape[:-1])
+        unknown_map = cur == mask_token_id
+        sampled_ids = torch.where(unknown_map, sampled_ids, cur)
+        ratio = 1.0 * (step + 1) / timesteps
+        mask_ratio = torch.cos(torch.tensor(ratio) * math.pi * 0.5)
+        selected_probs = torch.gather(probs, -1, sampled_ids.long()[..., None]).squeeze(-1)
+        selected_probs = torch.where(unknown_map, selected_probs, torch.finfo(selected_probs.dtype).max)
+        mask_len = (N * mask_ratio).floor().unsqueeze(0)
+        mask_len = torch.max(torch.tensor([1]), torch.min(unknown_map.sum(dim=-1, keepdim=True) - 1, mask_len))
+        temperature = temperature * (1.0 - ratio)
+        confidence = _log(selected_probs) + temperature * (-_log(-_log(rng.uniform_like(selected_probs, generator))))
+        cut_off = torch.gather(torch.sort(confidence, dim=-1).values, 1, mask_len.long())
+        masking = confidence < cut_off
+        input_ids[:, -(N + 1):-1] = torch.where(masking, mask_token_id, sampled_ids + tok_len)
+        cur = torch.where(masking, mask_token_id, sampled_ids)
+    return sampled_ids

@@ -82,3 +82,33 @@ class ReplayRng:
 
     def rand(self, shape, dtype, device, generator):
         return torch.rand(tuple(shape), dtype=dtype, generator=generator).to(device)
+
+
+# mmu_generate (M text sampler) stub-logit cases: tests/golden/mmu_traj.npz
+MMU_CASES = {
+    "mmu_plain": dict(max_new_tokens=16, steps=8, block_length=8, temperature=0.0, cfg_scale=0.0),
+    "mmu_cfg": dict(max_new_tokens=12, steps=6, block_length=4, temperature=0.0, cfg_scale=1.5),
+    "mmu_noisy": dict(max_new_tokens=8, steps=4, block_length=8, temperature=0.6, cfg_scale=0.0),
+}
+MMU_SHAPE = dict(B=2, P=7, V=2560, mask_id=126336)
+
+
+# t2i_generate (M text-to-image sampler) stub-logit cases: tests/golden/m_t2i_traj.npz
+M_T2I_CASES = {
+    "t2i_cfg": dict(B=2, temperature=1.0, timesteps=5, guidance_scale=2.0, uncond=True, known=0),
+    "t2i_plain": dict(B=1, temperature=0.7, timesteps=4, guidance_scale=0.0, uncond=False, known=3),
+}
+M_T2I_SHAPE = dict(P=9, N=16, resolution=6, text_vocab=2048, CB=512, mask_id=126336)
+
+
+def m_t2i_job(seed, B, known):
+    """[P prompt tokens][soi][N image slots][eoi]; `known` leading image slots already hold codebook tokens."""
+    sh = M_T2I_SHAPE
+    g = torch.Generator().manual_seed(seed)
+    prompt = torch.randint(0, 2000, (B, sh["P"]), generator=g)
+    unc = torch.randint(0, 2000, (B, sh["P"]), generator=g)
+    img = torch.full((B, sh["N"]), sh["mask_id"], dtype=torch.long)
+    if known:
+        img[:, :known] = torch.randint(0, sh["CB"], (B, known), generator=g) + sh["text_vocab"]
+    tail = torch.cat([torch.full((B, 1), 2040), img, torch.full((B, 1), 2041)], dim=1)
+    return torch.cat([prompt, tail], dim=1), torch.cat([unc, tail], dim=1)

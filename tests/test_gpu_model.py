@@ -523,3 +523,86 @@ def test_generate_image_real_tiny_model_runs_and_is_deterministic(tiny_model):
     assert int(a.min()) >= synth.TEXT_VOCAB and int(a.max()) < synth.TEXT_VOCAB + synth.CODEBOOK  # every slot was filled
     with pytest.raises(TypeError):
         generate_image(object(), job["prompt"], **kw)
+
+
+# ------------------------------------------------------------------------------- mmu_generate (M block-wise text sampler)
+from helpers import MMU_CASES, MMU_SHAPE  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(MMU_CASES))
+def test_mmu_generate_stub_trajectory_bit_exact(tiny_model, name):
+    """mmu_generate on stub logits (B = 2; CFG runs cond and prompt-masked copies as one batch-4 forward): ids of every
+    forward and the returned sequence equal the reference's MMadaModelLM.mmu_generate (tests/golden/mmu_traj.npz); the
+    float64 Gumbel noise of the temperature case is replayed from the same per-call seeded generators."""
+    from mmada_parallel_amd.generators.mmu_generator import mmu_generate
+    from oracle.interleave_oracle import SeededRng
+
+    z = np.load(os.path.join(GOLDEN, "mmu_traj.npz"))
+    seed, kw, sh = int(z[name + "_seed"]), MMU_CASES[name], MMU_SHAPE
+    stub = _stubbed(tiny_model, seed, sh["V"])
+
+    def fb(ids):  # one stub draw per forward, whatever its batch size (like the reference's single model call)
+        stub.n += 1
+        stub.calls.append(ids.cpu().clone())
+        stub._cur = stub_logits(seed, stub.n, ids.shape[0], ids.shape[1], sh["V"]).to(DEV)
+
+    stub.forward_body = fb
+    x = mmu_generate(stub, torch.from_numpy(z[name + "_idx"]), mask_id=sh["mask_id"], rng=SeededRng(seed), **kw)
+    assert torch.equal(torch.stack(stub.calls, 0), torch.from_numpy(z[name + "_calls"]))
+    assert torch.equal(x.cpu(), torch.from_numpy(z[name + "_x"]))
+
+
+def test_mmu_generate_real_tiny_model(tiny_model):
+    from mmada_parallel_amd.generators.mmu_generator import mmu_generate, mmu_generate_fast
+
+    idx = torch.randint(0, 1000, (2, 9), generator=torch.Generator().manual_seed(2))
+    a = mmu_generate(tiny_model, idx, max_new_tokens=16, steps=8, block_length=8)
+    b = mmu_generate(tiny_model, idx, max_new_tokens=16, steps=8, block_length=8)
+    assert a.shape == (2, 25) and torch.equal(a, b) and not bool((a == synth.MASK).any())
+    assert torch.equal(a[:, :9].cpu(), idx)
+    c = mmu_generate_fast(tiny_model, idx, max_new_tokens=16, steps=8, block_length=8, eot_token=int(a[0, 16]))
+    assert c.shape == (2, 25)
+    # the reference's attention_bias is dead code in its model (unmasked attention whatever the mask): same ids
+    d = mmu_generate(tiny_model, idx, max_new_tokens=16, steps=8, block_length=8,
+                     attention_mask=torch.tensor([[0] + [1] * 8, [1] * 9]))
+    assert torch.equal(a, d)
+
+
+# ---------------------------------------------------------------------- t2i_generate (M MaskGIT text-to-image sampler)
+from helpers import M_T2I_CASES, M_T2I_SHAPE, m_t2i_job  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(M_T2I_CASES))
+def test_m_t2i_generate_stub_trajectory_bit_exact(tiny_model, name):
+    """t2i_generate on stub logits with the reference's multinomial / uniform draws replayed: ids of every forward
+    (cond + uncond as one batch), the returned codebook ids and the in-place updated input_ids equal the reference's
+    MMadaModelLM.t2i_generate (tests/golden/m_t2i_traj.npz), incl. B = 2 and pre-filled (known) image tokens."""
+    from types import SimpleNamespace
+
+    from mmada_parallel_amd.generators.t2i_generator import t2i_generate
+    from oracle.interleave_oracle import SeededRng
+
+    z = np.load(os.path.join(GOLDEN, "m_t2i_traj.npz"))
+    seed, kw, sh = int(z[name + "_seed"]), M_T2I_CASES[name], M_T2I_SHAPE
+    V = sh["text_vocab"] + sh["CB"]
+    inp, unc = m_t2i_job(seed, kw["B"], kw["known"])
+    stub = _stubbed(tiny_model, seed, V)
+
+    def fb(ids):
+        stub.n += 1
+        stub.calls.append(ids.cpu().clone())
+        stub._cur = stub_logits(seed, stub.n, ids.shape[0], ids.shape[1], V).to(DEV)
+
+    stub.forward_body = fb
+
+    class Tok:
+        def __len__(self):
+            return sh["text_vocab"]
+
+    ids = t2i_generate(stub, input_ids=inp, uncond_input_ids=unc if kw["uncond"] else None, temperature=kw["temperature"],
+                       timesteps=kw["timesteps"], guidance_scale=kw["guidance_scale"], seq_len=sh["N"],
+                       mask_token_id=sh["mask_id"], resolution=sh["resolution"], codebook_size=sh["CB"],
+                       uni_prompting=SimpleNamespace(text_tokenizer=Tok()), rng=SeededRng(seed))
+    assert torch.equal(torch.stack(stub.calls, 0), torch.from_numpy(z[name + "_calls"]))
+    assert torch.equal(ids.cpu(), torch.from_numpy(z[name + "_ids"]))
+    assert torch.equal(inp, torch.from_numpy(z[name + "_final_input"]))

@@ -290,3 +290,53 @@ def test_t2i_trajectory_matches_reference(name):
     for i, (a, b) in enumerate(zip(trace, ref)):
         assert torch.equal(a, b), f"model call {i} differs"
     assert torch.equal(vq, torch.from_numpy(z[name + "_vq"]))
+
+
+# ---- mmu_generate (M block-wise text sampler, MMaDA-Parallel-M/models/modeling_mmada.py:618-692) ----------------------
+from helpers import MMU_CASES, MMU_SHAPE  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(MMU_CASES))
+def test_mmu_trajectory_matches_reference(name):
+    from oracle import interleave_oracle as io_
+
+    z = np.load(os.path.join(GOLDEN, "mmu_traj.npz"))
+    seed, kw, sh = int(z[name + "_seed"]), MMU_CASES[name], MMU_SHAPE
+    n = [0]
+
+    def model_fn(ids):
+        n[0] += 1
+        return stub_logits(seed, n[0], ids.shape[0], ids.shape[1], sh["V"])
+
+    trace = []
+    x = io_.mmu_generate(model_fn, torch.from_numpy(z[name + "_idx"]), kw["max_new_tokens"], kw["steps"], kw["block_length"],
+                         kw["temperature"], kw["cfg_scale"], sh["mask_id"], rng=io_.SeededRng(seed), trace=trace)
+    assert torch.equal(torch.stack(trace, 0), torch.from_numpy(z[name + "_calls"]))
+    assert torch.equal(x, torch.from_numpy(z[name + "_x"]))
+
+
+# ---- t2i_generate (M MaskGIT text-to-image sampler, MMaDA-Parallel-M/models/modeling_mmada.py:264-359) ----------------
+from helpers import M_T2I_CASES, M_T2I_SHAPE, m_t2i_job  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(M_T2I_CASES))
+def test_m_t2i_trajectory_matches_reference(name):
+    from oracle import interleave_oracle as io_
+
+    z = np.load(os.path.join(GOLDEN, "m_t2i_traj.npz"))
+    seed, kw, sh = int(z[name + "_seed"]), M_T2I_CASES[name], M_T2I_SHAPE
+    V = sh["text_vocab"] + sh["CB"]
+    inp, unc = m_t2i_job(seed, kw["B"], kw["known"])
+    n = [0]
+
+    def model_fn(ids):
+        n[0] += 1
+        return stub_logits(seed, n[0], ids.shape[0], ids.shape[1], V)
+
+    trace = []
+    ids = io_.t2i_generate(model_fn, inp, unc if kw["uncond"] else None, kw["temperature"], kw["timesteps"],
+                           kw["guidance_scale"], sh["N"], sh["mask_id"], sh["resolution"], sh["CB"], sh["text_vocab"],
+                           io_.SeededRng(seed), trace=trace)
+    assert torch.equal(torch.stack(trace, 0), torch.from_numpy(z[name + "_calls"]))
+    assert torch.equal(ids, torch.from_numpy(z[name + "_ids"]))
+    assert torch.equal(inp, torch.from_numpy(z[name + "_final_input"]))
