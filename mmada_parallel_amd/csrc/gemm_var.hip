@@ -4,6 +4,7 @@
 // generic in <BM, BN, BK, waves, stages> with a counted-vmcnt multi-stage pipeline:
 //     wait(tile t landed, (STAGES-2) tiles still in flight) ; barrier ; issue tile t+STAGES-1 ; multiply tile t
 // One raw s_barrier per K-tile; the LDS-DMA loads stay in flight across barriers (guide T3/T4).
+#include <algorithm>
 #include "kernels.h"
 
 namespace {
@@ -126,6 +127,152 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var_kernel(GemmArgs g
                 if (n < g.N) g.C[(size_t)m * g.ldc + n] = f2bf(acc[mi][ni][r]);
             }
         }
+}
+
+// Persistent data-parallel form of gemm_var_kernel: one workgroup per CU walks the tile sequence with stride gridDim
+// (same XCD-contiguous, K-lockstep order as the one-tile-per-workgroup launch); with PREFETCH the first STAGES-1
+// K-tiles of the NEXT output tile are requested before the epilogue stores of the current one.
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int MINW, bool PREFETCH>
+__global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_pers_kernel(GemmArgs g) {
+    constexpr int NW = WM * WN;
+    constexpr int RB = BK * 2, CPR = RB / 16, RPP = 64 / CPR, ROWS_PER_BANKROW = 256 / RB;
+    constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, STAGE_BYTES = A_BYTES + B_BYTES;
+    constexpr int PA = BM / RPP / NW, PB = BN / RPP / NW;
+    constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16, KK = BK / 32;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN, ntiles = ntm * ntn;
+    constexpr int GN = (BN >= 256) ? 4 : 8;
+    auto swz = [](int row) { return (row / ROWS_PER_BANKROW) % CPR; };
+    const int frow = lane & 15, fq = lane >> 4;
+    const int nk = g.K / BK;
+
+    const bf16_t* asrc[PA];
+    const bf16_t* wsrc[PB];
+    int m0 = 0, n0 = 0;
+    auto locate = [&](int tile, int& tm0, int& tn0) {
+        const int id = xcd_remap(tile, ntiles);
+        const int gsize = GN * ntm;
+        const int grp = id / gsize, rem = id - grp * gsize;
+        const int gn = min(GN, ntn - grp * GN);
+        tm0 = (rem / gn) * BM;
+        tn0 = (grp * GN + (rem - (rem / gn) * gn)) * BN;
+    };
+    auto point = [&](int tm0, int tn0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int row = (wave * PA + i) * RPP + lane / CPR;
+            asrc[i] = g.A + (size_t)min(tm0 + row, g.M - 1) * g.lda + ((lane % CPR) ^ swz(row)) * 8;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int row = (wave * PB + i) * RPP + lane / CPR;
+            wsrc[i] = g.W + (size_t)min(tn0 + row, g.N - 1) * g.ldw + ((lane % CPR) ^ swz(row)) * 8;
+        }
+    };
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kt * BK), (lptr_t)(base + (wave * PA + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + kt * BK), (lptr_t)(base + A_BYTES + (wave * PB + i) * 1024),
+                                             16, 0, 0);
+    };
+
+    int tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    locate(tile, m0, n0);
+    point(m0, n0);
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nk) stage(s, s);
+
+    while (true) {
+        f32x4 acc[FM][FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + STAGES - 2 < nk && !(PREFETCH && kt == 0))
+                wait_vm_lgkm<(STAGES - 2) * (PA + PB)>();
+            else
+                wait_vm_lgkm<0>();  // also drains the previous tile's epilogue stores (gfx9: one vmcnt for loads and stores)
+            if (kt + STAGES - 1 < nk) stage((kt + STAGES - 1) % STAGES, kt + STAGES - 1);
+            const char* At = smem + (kt % STAGES) * STAGE_BYTES;
+            const char* Wt = At + A_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                bf16x8 a[FM], b[FN];
+#pragma unroll
+                for (int mi = 0; mi < FM; ++mi) {
+                    const int row = wm * TM + mi * 16 + frow;
+                    a[mi] = *(const bf16x8*)(At + row * RB + (((kk * 4 + fq) ^ swz(row)) << 4));
+                }
+#pragma unroll
+                for (int ni = 0; ni < FN; ++ni) {
+                    const int row = wn * TN + ni * 16 + frow;
+                    b[ni] = *(const bf16x8*)(Wt + row * RB + (((kk * 4 + fq) ^ swz(row)) << 4));
+                }
+#pragma unroll
+                for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < FN; ++ni)
+                        acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+            }
+        }
+        const int cm0 = m0, cn0 = n0;
+        tile += gridDim.x;
+        const bool more = tile < ntiles;
+        __syncthreads();  // every wave has read the last K-tile: the ring may be refilled
+        if (more) {
+            locate(tile, m0, n0);
+            point(m0, n0);
+            if (PREFETCH) {
+#pragma unroll
+                for (int s = 0; s < STAGES - 1; ++s)
+                    if (s < nk) stage(s, s);
+            }
+        }
+        const int mrow0 = cm0 + wm * TM + fq * 4, ncol0 = cn0 + wn * TN + frow;
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mrow0 + mi * 16 + r;
+                if (m >= g.M) continue;
+#pragma unroll
+                for (int ni = 0; ni < FN; ++ni) {
+                    const int n = ncol0 + ni * 16;
+                    if (n < g.N) g.C[(size_t)m * g.ldc + n] = f2bf(acc[mi][ni][r]);
+                }
+            }
+        if (!more) break;
+        if (!PREFETCH) {
+#pragma unroll
+            for (int s = 0; s < STAGES - 1; ++s)
+                if (s < nk) stage(s, s);
+        }
+    }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int MINW, bool PREFETCH>
+int launch_pers(const GemmArgs& g, hipStream_t s) {
+    constexpr int LDS = STAGES * (BM + BN) * BK * 2;
+    static bool attr_set = false;
+    auto fn = gemm_pers_kernel<BM, BN, BK, WM, WN, STAGES, MINW, PREFETCH>;
+    if (!attr_set) {
+        MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int ntiles = ((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN);
+    hipLaunchKernelGGL(fn, dim3(std::min(ntiles, 256)), dim3(64 * WM * WN), LDS, s, g);
+    MM_CHECK_HIP(hipGetLastError());
+    return 0;
 }
 
 // Same pipeline with v_mfma_f32_32x32x16_bf16 (one ds_read_b128 per 32x16 operand fragment; C layout
@@ -875,6 +1022,8 @@ int launch_gemm_variant(int variant, const GemmArgs& g, hipStream_t s) {
         case 35: return launch_pp2<2>(g, s);
         case 32: return launch_pp<false, 1>(g, s);
         case 33: return launch_pp<false, 2>(g, s);
+        case 60: return launch_pers<256, 256, 64, 4, 4, 2, 4, false>(g, s);  // v10, persistent
+        case 61: return launch_pers<256, 256, 64, 4, 4, 2, 4, true>(g, s);   // ... + next-tile prefetch under the epilogue
         case 20: return launch_big<4, false>(g, s);
         case 21: return launch_big<4, true>(g, s);
         case 22: return launch_big<5, true>(g, s);
