@@ -106,6 +106,11 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # MMADA_BENCH_ONE_GPU=1 (test rigs with a single GPU): every rank uses cuda:0 and the collective runs over gloo, so
+    # the multi-process tensor-parallel path can be exercised end to end; such a line is marked and is not a measurement.
+    one_gpu = os.environ.get("MMADA_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or "RANK" in os.environ  # launched by torch.distributed.run: one rank per GPU over RCCL
@@ -114,14 +119,17 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from mmada_parallel_amd import LLaDAForMultiModalGeneration, abi, generate_ti2ti, synth
 
     cfg = dict(synth.CFG_8B)
     if args.layers:
         cfg["n_layers"] = args.layers
-    reduced = args.text_steps != 128 or args.timesteps != 64 or args.layers is not None
+    reduced = args.text_steps != 128 or args.timesteps != 64 or args.layers is not None or one_gpu
     full = synth.full_config(cfg)
     tp = world if args.parallelism == "tp" else 1
     B = tp  # weak scaling: one job per rank-equivalent; tp: model sharded over all ranks, dp: replicas
@@ -140,7 +148,7 @@ def main():
         return generate_ti2ti(model, ids, job["text_start"], job["text_end"], job["image_start"], job["seq_len"],
                               job["newline_every"], text_steps=args.text_steps, timesteps=args.timesteps, temperature=0.0,
                               text_temperature=0.0, cfg_scale=0.0, cfg_img=4.0, uncon_text=job["uncon_text"],
-                              uncon_image=job["uncon_image"])
+                              uncon_image=job["uncon_image"], return_state=True)
 
     def barrier():
         if use_dist:
@@ -154,15 +162,20 @@ def main():
     abi.check(lib.mmada_profile_begin(h, cfg["n_layers"] // 2), "profile_begin")
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        vq, _ = run_once()
+        vq, _, final_ids = run_once()
     barrier()
     dt = time.perf_counter() - t0
     cnt, ms, fl = (C.c_int32 * 5)(), (C.c_double * 5)(), (C.c_double * 5)()
     abi.check(lib.mmada_profile_end(h, cnt, ms, fl), "profile_end")
+    ranks_agree = None
     if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
+        # outside the timed region: under tensor parallelism every rank must have sampled the same image tokens
+        allv = [None] * world
+        dist.all_gather_object(allv, final_ids.tolist())  # all B jobs, before the one random fill of the read-out
+        ranks_agree = all(a == allv[0] for a in allv) if tp > 1 else None
 
     if rank == 0:
         from mmada_parallel_amd.generators.parallel_generator import image_step_indices
@@ -188,6 +201,7 @@ def main():
                        "text_steps": args.text_steps, "timesteps": args.timesteps, "n_layers": cfg["n_layers"],
                        "algorithmic_pflop_per_image": fl_img / 1e15,
                        "job_mfma_frac": value * fl_img / 1e12 / (world * MFMA_BF16_PEAK_TFLOPS),
+                       "tp_ranks_agree": ranks_agree,
                        "kernels": kinds},
             "roofline": {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_traffic(KIND_NAMES[dom])},

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, SAMPLER_CASES, STUB_CB, STUB_TEXT_VOCAB, bits, from_bits, stub_logits, tiny_job, tiny_sd
+from helpers import GOLDEN, ROOT, SAMPLER_CASES, STUB_CB, STUB_TEXT_VOCAB, bits, from_bits, stub_logits, tiny_job, tiny_sd
 from mmada_parallel_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -606,3 +606,27 @@ def test_m_t2i_generate_stub_trajectory_bit_exact(tiny_model, name):
     assert torch.equal(torch.stack(stub.calls, 0), torch.from_numpy(z[name + "_calls"]))
     assert torch.equal(ids.cpu(), torch.from_numpy(z[name + "_ids"]))
     assert torch.equal(inp, torch.from_numpy(z[name + "_final_input"]))
+
+
+# ------------------------------------------------------------------ multi-process tensor parallel, end to end (one GPU)
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_multi_rank_tensor_parallel_on_one_gpu(world):
+    """bench.py's N-rank path (one process per rank, TP = N, N jobs, micro-batched async all-reduce) launched exactly as
+    the driver launches it, except that all ranks share cuda:0 and the collective runs over gloo (MMADA_BENCH_ONE_GPU=1):
+    every rank must finish, sample identical tokens (tp_ranks_agree) and rank 0 must print one JSON line."""
+    import json
+    import subprocess
+    import sys
+
+    env = dict(os.environ, MMADA_BENCH_ONE_GPU="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+           "127.0.0.1", "--master-port", str(29600 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world),
+           "--steps", "1", "--warmup", "0", "--layers", "2", "--text-steps", "8", "--timesteps", "4", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and out["config"]["parallelism"] == f"tp{world}" and out["config"]["global_batch"] == world
+    assert out["config"]["tp_ranks_agree"] is True
+    assert out["value"] > 0 and "REDUCED" in out["config"]["workload"]
