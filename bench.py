@@ -33,12 +33,29 @@ def body_flops(cfg, L):
     return nl * (lin + 4.0 * L * L * d)
 
 
-def job_flops(cfg, L, T, N, text_steps, n_img_steps, V, CB):
-    """Algorithmic FLOPs of one image: LM head counted on the consumed rows/columns only."""
+def last_block_saving(cfg, L, lo, hi):
+    """FLOPs the last block does not spend when only rows [lo, hi) are consumed (mmada_set_consumed_rows): attention
+    queries, attn_out and the MLP run on the window (start rounded down to 32 rows); QKV still covers every row."""
+    d, F = cfg["d_model"], cfg["mlp_hidden_size"]
+    w = hi - (lo & ~31)
+    if w >= L:
+        return 0.0
+    return (L - w) * (2.0 * (d * d + 3 * d * F) + 4.0 * L * d)
+
+
+def job_flops(cfg, L, T, N, text_steps, n_img_steps, V, CB, job=None):
+    """FLOPs of one image actually required: LM head on the consumed rows/columns only and, when `job`
+    is given, the last block on the consumed rows only — skipped work is not counted as achieved."""
     fb = body_flops(cfg, L)
     head_text = 2.0 * T * cfg["d_model"] * V
     head_img = 2.0 * N * cfg["d_model"] * CB
-    return text_steps * (fb + head_text) + n_img_steps * 2 * fb + n_img_steps * 3 * head_img
+    total = text_steps * (fb + head_text) + n_img_steps * 2 * fb + n_img_steps * 3 * head_img
+    if job is not None:
+        img = (job["image_start"], job["text_start"] - 1)  # image span incl. newlines, text follows after <eoi>
+        total -= (text_steps - n_img_steps) * last_block_saving(cfg, L, job["text_start"], job["text_end"])
+        total -= n_img_steps * last_block_saving(cfg, L, img[0], job["text_end"])
+        total -= n_img_steps * 2 * last_block_saving(cfg, L, img[0], img[1])
+    return total
 
 
 def cpu_baseline(cfg, job, sample_layers=2, reps=2):
@@ -181,7 +198,9 @@ def main():
         from mmada_parallel_amd.generators.parallel_generator import image_step_indices
 
         n_img = len(set(image_step_indices(args.text_steps, args.timesteps)))
-        fl_img = job_flops(cfg, L, T, N, args.text_steps, n_img, cfg["embedding_size"], synth.CODEBOOK)
+        windowed = os.environ.get("MMADA_NO_WINDOW") != "1"
+        fl_img = job_flops(cfg, L, T, N, args.text_steps, n_img, cfg["embedding_size"], synth.CODEBOOK,
+                           job if windowed else None)
         images = args.steps * world  # tp: B = world jobs in one group; dp: one job on each of `world` replicas
         value = images / dt
         kinds = {}

@@ -102,6 +102,14 @@ int mmada_forward_body(mmada_handle* h, const int64_t* ids /*device [B,L]*/, int
 int mmada_head_rows(mmada_handle* h, const int32_t* rows, int R, int col_begin, int col_end,
                     void* logits_out, void* stream);
 
+/* Declare which residual-stream rows the caller will read after the forwards that follow: only l in
+ * [row_begin, row_end) of every sequence (e.g. the image + text span of generate_ti2ti; the prompt and the input image
+ * are never decoded).  The LAST block then runs attention queries, attn_out and the MLP on those rows only — every
+ * earlier block, and the last block's keys/values, still cover the whole sequence, so the consumed rows are
+ * bit-identical to a full forward.  mmada_head_rows must then only be given rows inside the window; mmada_read_stream
+ * and mmada_forward refuse to run.  row_begin == row_end clears the window.  The setting persists across forwards. */
+int mmada_set_consumed_rows(mmada_handle* h, int row_begin, int row_end);
+
 /* Drop-in full forward: logits_out bf16 device [B, L, vocab] (generators/parallel_generator.py:178,263,264). */
 int mmada_forward(mmada_handle* h, const int64_t* ids, int B, int L, void* logits_out, void* stream);
 

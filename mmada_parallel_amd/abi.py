@@ -37,6 +37,7 @@ SIGNATURES = {
     "mmada_bind_layer": (c_int, [c_void_p, c_int] + [c_void_p] * 9 + [c_void_p]),
     "mmada_workspace_bytes": (c_size_t, [c_void_p, c_int, c_int]),
     "mmada_set_workspace": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "mmada_set_consumed_rows": (c_int, [c_void_p, c_int, c_int]),
     "mmada_forward_body": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mmada_head_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mmada_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),

@@ -50,6 +50,10 @@ struct mmada_handle {
     bf16_t *x = nullptr, *y = nullptr, *xn = nullptr, *att = nullptr, *hbuf = nullptr, *q = nullptr, *k = nullptr,
            *vT = nullptr, *xg = nullptr;
     int32_t* rows_all = nullptr;
+    // consumed-row window (mmada_set_consumed_rows): requested [win_beg, win_end) per sequence; while a forward whose
+    // last block ran windowed is resident, the stream is compact: cur_W rows per sequence starting at row cur_beg
+    int win_beg = 0, win_end = 0;
+    int cur_W = 0, cur_beg = 0, Mcur = 0;
     // live timing (mmada_profile_begin/end)
     int prof_layer = -1;
     struct ProfRec { int kind; hipEvent_t a, b; double flops; };
@@ -266,6 +270,7 @@ int mmada_embed(mmada_handle* h, const int64_t* ids, int B, int L, void* stream)
     hipStream_t s = (hipStream_t)stream;
     if (check_bound(h)) return 1;
     if (apply_carve(h, B, L, s)) return 1;
+    h->cur_W = 0; h->cur_beg = 0; h->Mcur = h->M;
     return launch_embed(ids, h->wte, h->x, B, L, h->Lp, h->cfg.d_model, h->cfg.vocab, s);
 }
 
@@ -287,21 +292,37 @@ int mmada_attn_partial(mmada_handle* h, int layer, void* stream) {
         ProfScope p(h, layer, 0, 2.0 * rows * g.N * g.K, s);
         if (launch_gemm(EPI_QKV, g, s)) return 1;
     }
+    // last block + consumed-row window: only the rows the caller will read are attended / projected (bit-identical on
+    // them: the window start is rounded down to the 32-query wave granule, so every wave sees the queries it saw before)
+    int wbeg = 0, W = 0;
+    if (layer == h->cfg.n_layers - 1 && h->win_end > h->win_beg) {
+        if (h->win_end > h->L) return mm_fail("forward: consumed rows [%d,%d) exceed L=%d", h->win_beg, h->win_end, h->L);
+        wbeg = h->win_beg & ~31;
+        W = h->win_end - wbeg;
+        if (W >= h->L) { wbeg = 0; W = 0; }  // nothing to skip
+    }
+    const int Mo = W ? h->B * W : h->M;
+    const double orows = W ? (double)h->B * W : rows;
     {
-        ProfScope p(h, layer, 1, 4.0 * h->B * h->hq_l * (double)h->L * h->L * 128.0, s);
-        if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->Lp, h->Lkv, h->Lp,
-                             h->hq_l * 128, s)) return 1;
+        ProfScope p(h, layer, 1, 4.0 * h->hq_l * orows * h->L * 128.0, s);
+        if (W) {
+            if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->win_end, h->Lkv, W,
+                                 h->hq_l * 128, s, wbeg)) return 1;
+        } else if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->Lp, h->Lkv, h->Lp,
+                                    h->hq_l * 128, s)) return 1;
     }
     GemmArgs o{};
     o.A = h->att; o.W = lw.wo; o.C = h->y;
-    o.M = h->M; o.N = d; o.K = h->hq_l * 128;
+    o.M = Mo; o.N = d; o.K = h->hq_l * 128;
     o.lda = o.K; o.ldw = o.K; o.ldc = d;
     o.resid = h->x; o.ldr = d; o.resid_mod = h->cfg.tp_size; o.resid_rank = h->cfg.tp_rank;
+    if (W) { o.rwin = W; o.rlp = h->Lp; o.rbeg = wbeg; }
     {
-        ProfScope p(h, layer, 2, 2.0 * rows * o.N * o.K, s);
+        ProfScope p(h, layer, 2, 2.0 * orows * o.N * o.K, s);
         if (launch_gemm(EPI_RESID, o, s)) return 1;
     }
     std::swap(h->x, h->y);
+    if (W) { h->cur_W = W; h->cur_beg = wbeg; h->Mcur = Mo; }
     return 0;
 }
 
@@ -311,19 +332,19 @@ int mmada_mlp_partial(mmada_handle* h, int layer, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const LayerWeights& lw = h->layers[layer];
     const int d = h->cfg.d_model;
-    if (launch_rmsnorm(h->x, lw.ff_norm, h->xn, h->M, d, h->cfg.rms_eps, s)) return 1;
+    if (launch_rmsnorm(h->x, lw.ff_norm, h->xn, h->Mcur, d, h->cfg.rms_eps, s)) return 1;
     GemmArgs g{};
     g.A = h->xn; g.W = lw.wgu; g.C = h->hbuf;
-    g.M = h->M; g.N = 2 * h->f_l; g.K = d;
+    g.M = h->Mcur; g.N = 2 * h->f_l; g.K = d;
     g.lda = d; g.ldw = d; g.ldc = h->f_l;
-    const double rows = (double)h->B * h->L;
+    const double rows = h->cur_W ? (double)h->Mcur : (double)h->B * h->L;
     {
         ProfScope p(h, layer, 3, 2.0 * rows * g.N * g.K, s);
         if (launch_gemm(EPI_SWIGLU, g, s)) return 1;
     }
     GemmArgs o{};
     o.A = h->hbuf; o.W = lw.wdown; o.C = h->y;
-    o.M = h->M; o.N = d; o.K = h->f_l;
+    o.M = h->Mcur; o.N = d; o.K = h->f_l;
     o.lda = h->f_l; o.ldw = h->f_l; o.ldc = d;
     o.resid = h->x; o.ldr = d; o.resid_mod = h->cfg.tp_size; o.resid_rank = h->cfg.tp_rank;
     {
@@ -358,7 +379,7 @@ int mmada_profile_end(mmada_handle* h, int32_t* count_out, double* ms_out, doubl
 }
 
 void* mmada_stream_ptr(mmada_handle* h) { return h ? (void*)h->x : nullptr; }
-size_t mmada_stream_bytes(const mmada_handle* h) { return h ? (size_t)h->M * h->cfg.d_model * 2 : 0; }
+size_t mmada_stream_bytes(const mmada_handle* h) { return h ? (size_t)h->Mcur * h->cfg.d_model * 2 : 0; }
 
 int mmada_forward_body(mmada_handle* h, const int64_t* ids, int B, int L, void* stream) {
     if (!h) return mm_fail("mmada_forward_body: null handle");
@@ -382,7 +403,10 @@ int mmada_head_rows(mmada_handle* h, const int32_t* rows, int R, int col_begin, 
     if (col_begin < 0 || col_end > h->cfg.vocab || col_begin >= col_end) return mm_fail("mmada_head_rows: bad column range");
     hipStream_t s = (hipStream_t)stream;
     const int d = h->cfg.d_model;
-    if (launch_rmsnorm_gather(h->x, h->ln_f, h->xg, rows, R, h->L, h->Lp, d, h->cfg.rms_eps, s)) return 1;
+    // a windowed forward left the stream compact: row (b, l) sits at b*cur_W + l - cur_beg; rows outside the window the
+    // caller declared with mmada_set_consumed_rows were never computed and must not be requested
+    if (launch_rmsnorm_gather(h->x, h->ln_f, h->xg, rows, R, h->L, h->cur_W ? h->cur_W : h->Lp, d, h->cfg.rms_eps, s,
+                              h->cur_beg)) return 1;
     GemmArgs g{};
     g.A = h->xg; g.W = h->lm_head + (size_t)col_begin * d; g.C = (bf16_t*)logits_out;
     g.M = R; g.N = col_end - col_begin; g.K = d;
@@ -390,7 +414,16 @@ int mmada_head_rows(mmada_handle* h, const int32_t* rows, int R, int col_begin, 
     return launch_gemm(EPI_STORE, g, s);
 }
 
+int mmada_set_consumed_rows(mmada_handle* h, int row_begin, int row_end) {
+    if (!h) return mm_fail("mmada_set_consumed_rows: null handle");
+    if (row_begin < 0 || row_end < row_begin) return mm_fail("mmada_set_consumed_rows: bad range [%d,%d)", row_begin, row_end);
+    h->win_beg = row_begin;
+    h->win_end = row_end;  // row_begin == row_end: no window (every row is computed)
+    return 0;
+}
+
 int mmada_forward(mmada_handle* h, const int64_t* ids, int B, int L, void* logits_out, void* stream) {
+    if (h && h->win_end > h->win_beg) return mm_fail("mmada_forward: returns every row; clear mmada_set_consumed_rows first");
     if (mmada_forward_body(h, ids, B, L, stream)) return 1;
     if (launch_iota_rows(h->rows_all, B * L, (hipStream_t)stream)) return 1;
     return mmada_head_rows(h, h->rows_all, B * L, 0, h->cfg.vocab, logits_out, stream);
@@ -398,6 +431,7 @@ int mmada_forward(mmada_handle* h, const int64_t* ids, int B, int L, void* logit
 
 int mmada_read_stream(mmada_handle* h, void* out, void* stream) {
     if (!h || h->M == 0 || !out) return mm_fail("mmada_read_stream: no forward resident");
+    if (h->cur_W) return mm_fail("mmada_read_stream: the resident stream only holds rows [%d,%d) of each sequence", h->cur_beg, h->cur_beg + h->cur_W);
     return launch_unpad_rows(h->x, (bf16_t*)out, h->B, h->L, h->Lp, h->cfg.d_model, (hipStream_t)stream);
 }
 

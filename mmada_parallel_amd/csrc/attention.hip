@@ -48,6 +48,7 @@ struct AttnArgs {
     const bf16_t* vT;
     bf16_t* out;
     int Hq, Hkv, L, Lq_rows, Lkv, out_rows_per_batch, ld_out;
+    int q_begin;  // first query row (multiple of 32); output row of query r is b*out_rows_per_batch + r - q_begin
     float scale_log2e;
 };
 
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const bf16_t* Kp = a.k + (size_t)(b * a.Hkv + hkv) * a.Lkv * 128;
     const bf16_t* Vp = a.vT + (size_t)(b * a.Hkv + hkv) * 128 * a.Lkv;
 
-    const int q_row = qb * QB + wave * 32 + ql;
+    const int q_row = a.q_begin + qb * QB + wave * 32 + ql;
     const int q_ld = min(q_row, a.Lkv - 1);
     bf16x8 qf[8];
 #pragma unroll
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (q_row < a.Lq_rows) {
-        bf16_t* orow = a.out + ((size_t)b * a.out_rows_per_batch + q_row) * a.ld_out + h * 128;
+        bf16_t* orow = a.out + ((size_t)b * a.out_rows_per_batch + q_row - a.q_begin) * a.ld_out + h * 128;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
 #pragma unroll
@@ -200,10 +201,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
 }  // namespace
 
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int B, int Hq, int Hkv, int L,
-                     int Lq_rows, int Lkv, int out_rows_per_batch, int ld_out, hipStream_t s) {
+                     int Lq_rows, int Lkv, int out_rows_per_batch, int ld_out, hipStream_t s, int q_begin) {
     if (L <= 0 || B <= 0) return 0;
     if (Lkv % 64 || Lkv < L) return mm_fail("attention: Lkv=%d must be a multiple of 64 and >= L=%d", Lkv, L);
     if (Hq % Hkv) return mm_fail("attention: n_heads %% n_kv_heads != 0");
+    if (q_begin < 0 || (q_begin & 31) || q_begin >= Lq_rows) return mm_fail("attention: bad q_begin=%d", q_begin);
     static bool attr_set = false;
     if (!attr_set) {
         MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
@@ -212,9 +214,9 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     AttnArgs a;
     a.q = q; a.k = k; a.vT = vT; a.out = out;
     a.Hq = Hq; a.Hkv = Hkv; a.L = L; a.Lq_rows = Lq_rows; a.Lkv = Lkv;
-    a.out_rows_per_batch = out_rows_per_batch; a.ld_out = ld_out;
+    a.out_rows_per_batch = out_rows_per_batch; a.ld_out = ld_out; a.q_begin = q_begin;
     a.scale_log2e = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
-    hipLaunchKernelGGL(attn_fwd_kernel, dim3((Lq_rows + QB - 1) / QB, Hq, B), dim3(256), ATT_LDS, s, a);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3((Lq_rows - q_begin + QB - 1) / QB, Hq, B), dim3(256), ATT_LDS, s, a);
     MM_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -174,6 +174,11 @@ MM_DEVICE void epilogue(const GemmArgs& g, int m0, int n0,
                 if (m >= g.M) continue;
                 // wave-uniform: the 16 rows of a fragment share one residual owner
                 const bool add = EPI == EPI_RESID && (g.resid_mod == 1 || ((m >> 4) % g.resid_mod) == g.resid_rank);
+                size_t rrow = (size_t)m;  // residual row (compact -> full layout when a row window is active)
+                if (EPI == EPI_RESID && g.rwin) {
+                    const int bb = m / g.rwin;
+                    rrow = (size_t)bb * g.rlp + g.rbeg + (m - bb * g.rwin);
+                }
 #pragma unroll
                 for (int ni = 0; ni < FN; ++ni) {
                     const int n = wcol0 + ni * 16 + frow;
@@ -181,7 +186,7 @@ MM_DEVICE void epilogue(const GemmArgs& g, int m0, int n0,
                     float v = acc[mi][ni][r];
                     if constexpr (EPI == EPI_RESID) {
                         v = bfround(v);
-                        if (add) v = bf2f(g.resid[(size_t)m * g.ldr + n]) + v;
+                        if (add) v = bf2f(g.resid[rrow * g.ldr + n]) + v;
                     }
                     g.C[(size_t)m * g.ldc + n] = f2bf(v);
                 }

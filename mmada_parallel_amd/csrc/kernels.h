@@ -18,6 +18,9 @@ struct GemmArgs {
     const bf16_t* resid;
     int ldr;
     int resid_mod, resid_rank;
+    // Row map of the residual read (0 = identity): C/A rows are compact [b*rwin + i], the residual is read from the
+    // full-layout row b*rlp + rbeg + i (last block of a forward whose consumer only reads a row window).
+    int rwin, rlp, rbeg;
     // EPI_QKV: rows are (b, l) with m = b*Lp + l; columns are [q heads | k heads | v heads] x 128
     bf16_t* q;         // [B, Hq , Lkv, 128]
     bf16_t* k;         // [B, Hkv, Lkv, 128]
@@ -34,8 +37,9 @@ int launch_gemm_variant(int variant, const GemmArgs& g, hipStream_t s);  // gemm
 int launch_embed(const int64_t* ids, const bf16_t* wte, bf16_t* x, int B, int L, int Lp, int d, int vocab, hipStream_t s);
 int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int d, float eps, hipStream_t s);
 // gathered rmsnorm: out[r] = rmsnorm(x[map(rows[r])]) where rows[r] = b*L + l and x rows are b*Lp + l
-int launch_rmsnorm_gather(const bf16_t* x, const bf16_t* w, bf16_t* out, const int32_t* rows, int R, int L, int Lp,
-                          int d, float eps, hipStream_t s);
+// x row of the flat index b*L + l is b*row_stride + l - row_off (row_stride = Lp, row_off = 0 for the full layout)
+int launch_rmsnorm_gather(const bf16_t* x, const bf16_t* w, bf16_t* out, const int32_t* rows, int R, int L, int row_stride,
+                          int d, float eps, hipStream_t s, int row_off = 0);
 int launch_rope_table(float* cos_t, float* sin_t, const float* inv_freq_dev, int max_seq, hipStream_t s);
 int launch_unpad_rows(const bf16_t* x, bf16_t* out, int B, int L, int Lp, int d, hipStream_t s);
 int launch_iota_rows(int32_t* rows, int n, hipStream_t s);
@@ -52,7 +56,7 @@ int launch_lfq_gather(const int64_t* idx, void* out, int B, int N, int nbits, in
 
 // attention.hip:  q [B,Hq,Lkv,128], k [B,Hkv,Lkv,128], vT [B,Hkv,128,Lkv] -> out rows (b*Lp_out + l) x (Hq*128)
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int B, int Hq, int Hkv, int L,
-                     int Lq_rows, int Lkv, int out_row_stride_per_batch, int ld_out, hipStream_t s);
+                     int Lq_rows, int Lkv, int out_row_stride_per_batch, int ld_out, hipStream_t s, int q_begin = 0);
 
 // sampler.hip
 int launch_text_select(const bf16_t* logits, const bf16_t* noisy, const bf16_t* unc, float text_cfg, const int32_t* x0_in,

@@ -12,6 +12,7 @@ All per-step counts (text k, image mask_len) are schedule-determined (SURVEY A.5
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -152,15 +153,21 @@ def _ti2ti_steps(
         uncon_image = uncon_image.to(device=device, dtype=torch.long)
 
     masked_left = remaining_text.clone()
+    # rows of the residual stream each forward is read at (host-side): the last block only computes those
+    windowed = os.environ.get("MMADA_NO_WINDOW") != "1"
+    img_win = (pos_list[0], pos_list[-1] + 1)
     for step in range(text_steps):
         # ===== forward: conditional logits (reference :177-178), only the rows/columns that are consumed =====
-        model.forward_body(ids)
-        st = abi.stream_ptr()
         is_img = step in img_steps
+        need_text = int(masked_left.sum()) > 0
+        lo = min(img_win[0] if is_img else L, text_start if need_text or not is_img else L)
+        hi = max(img_win[1] if is_img else 0, text_end if need_text or not is_img else 0)
+        model.forward_body(ids, consumed=(lo, hi) if windowed else None)
+        st = abi.stream_ptr()
         cond_vq = model.head_rows(img_rows_1, text_vocab_size, text_vocab_size + codebook_size) if is_img else None
 
         # ===== text step (reference :181-217) =====
-        if int(masked_left.sum()) > 0:
+        if need_text:
             text_logits = model.head_rows(text_rows, 0, V)  # [B*T, V]
             noisy = None
             if text_temperature != 0:
@@ -182,7 +189,8 @@ def _ti2ti_steps(
                     unc[:B, :uncon_text.shape[1]] = uncon_text
                 if uncon_image is not None:
                     unc[B:, :uncon_image.shape[1]] = uncon_image
-                model.forward_body(unc)  # both uncond forwards run whenever either scale > 0 (reference :243)
+                # both uncond forwards run whenever either scale > 0 (reference :243); only their image rows are read
+                model.forward_body(unc, consumed=img_win if windowed else None)
                 unc_vq = model.head_rows(img_rows_2, text_vocab_size, text_vocab_size + codebook_size)
                 ut, ui = unc_vq[:B * N], unc_vq[B * N:]
             elif cfg_scale != 0.0 or cfg_img != 0.0:

@@ -177,8 +177,12 @@ class LLaDAForMultiModalGeneration:
         return self._handle1
 
     # ---- forward ---------------------------------------------------------------------------------------------------
-    def forward_body(self, input_ids: torch.Tensor) -> None:
+    def forward_body(self, input_ids: torch.Tensor, consumed: Optional[tuple] = None) -> None:
         """Embedding + all blocks; the final residual stream stays resident for head_rows().
+
+        consumed = (row_begin, row_end): the caller promises to read only rows [row_begin, row_end) of each sequence
+        through head_rows(); the last block then skips the other rows (mmada_set_consumed_rows; bit-identical on the
+        consumed rows).  None = every row.
 
         Tensor parallel (tp_size > 1): after each of the two row-parallel GEMMs of a block the partial residual
         stream is all-reduced over RCCL.  With B >= 2 the batch is split into two micro-batches living in two
@@ -189,6 +193,12 @@ class LLaDAForMultiModalGeneration:
         st = abi.stream_ptr()
         microbatch = B >= 2 and (self.tp_size > 1 or os.environ.get("MMADA_MICROBATCH") == "1")
         self._split = None
+        lo, hi = (int(consumed[0]), int(consumed[1])) if consumed is not None else (0, 0)
+        if consumed is not None and not 0 <= lo < hi <= L:
+            raise ValueError(f"consumed rows {consumed} outside [0, {L})")
+        self._consumed = (lo, hi) if consumed is not None else None
+        for lane in ((0, 1) if microbatch else (0,)):
+            abi.check(self._lib.mmada_set_consumed_rows(self._lane_handle(lane), lo, hi), "mmada_set_consumed_rows")
         if not microbatch:
             self._ensure_ws(B, L)
             if self.tp_size == 1:
@@ -241,6 +251,9 @@ class LLaDAForMultiModalGeneration:
 
         `rows` must be batch-major with the same number of rows per batch element (what generate_ti2ti builds)."""
         rows = rows.to(device=self.device, dtype=torch.int32).contiguous()
+        if os.environ.get("MMADA_CHECK_ROWS") == "1" and getattr(self, "_consumed", None) is not None and rows.numel():
+            l = rows % self._shape[1]  # debug aid (forces a device sync): rows must lie inside the declared window
+            assert int(l.min()) >= self._consumed[0] and int(l.max()) < self._consumed[1], "head_rows outside forward_body(consumed=...)"
         out = torch.empty((rows.numel(), col_end - col_begin), dtype=torch.bfloat16, device=self.device)
         st = abi.stream_ptr()
         if getattr(self, "_split", None) is None:

@@ -83,7 +83,7 @@ def test_sampler_counting_invariants_full_size(block8b):
         def __del__(self):
             pass
 
-        def forward_body(self, ids):
+        def forward_body(self, ids, consumed=None):
             self.n += 1
             if ids.shape[0] == 1:
                 snaps.append(ids.cpu().clone())

@@ -176,7 +176,7 @@ def _stubbed(tiny_model, seed, V):
         def __del__(self):
             pass
 
-        def forward_body(self, ids):
+        def forward_body(self, ids, consumed=None):
             B = ids.shape[0]
             chunks = []
             for b in range(B):  # the reference calls the model once per sequence: one stub draw per sequence
@@ -630,3 +630,57 @@ def test_bench_multi_rank_tensor_parallel_on_one_gpu(world):
     assert out["n_gpus"] == world and out["config"]["parallelism"] == f"tp{world}" and out["config"]["global_batch"] == world
     assert out["config"]["tp_ranks_agree"] is True
     assert out["value"] > 0 and "REDUCED" in out["config"]["workload"]
+
+
+# ------------------------------------------------------------------------------- consumed-row window of the last block
+@pytest.mark.parametrize("B,win", [(1, (37, 60)), (2, (33, 70)), (1, (64, 70)), (2, (5, 40))])
+def test_consumed_row_window_is_bit_identical_on_the_consumed_rows(tiny_model, B, win):
+    """forward_body(consumed=(lo, hi)): the last block skips the other rows; logits of the consumed rows must equal the
+    full forward's BIT FOR BIT (same K order in every GEMM, same 32-query wave grouping in attention)."""
+    from mmada_parallel_amd import abi
+
+    job = tiny_job()
+    ids = job["input_ids"].repeat(B, 1).to(DEV)
+    if B == 2:
+        ids[1, :6] = torch.arange(50, 56, device=DEV)
+    L = ids.shape[1]
+    lo, hi = win
+    assert hi <= L
+    rows = (torch.arange(B, device=DEV)[:, None] * L + torch.arange(lo, hi, device=DEV)[None, :]).reshape(-1).to(torch.int32)
+    tiny_model.forward_body(ids)
+    full = tiny_model.head_rows(rows, synth.TEXT_VOCAB - 64, synth.TEXT_VOCAB + 448).clone()
+    os.environ["MMADA_CHECK_ROWS"] = "1"
+    try:
+        tiny_model.forward_body(ids, consumed=(lo, hi))
+        got = tiny_model.head_rows(rows, synth.TEXT_VOCAB - 64, synth.TEXT_VOCAB + 448)
+        assert torch.equal(got, full)
+        with pytest.raises(abi.MmadaError):
+            tiny_model.hidden_state()  # the resident stream only holds the window
+        with pytest.raises(AssertionError):
+            tiny_model.head_rows(torch.tensor([max(0, (lo & ~31) - 1)], dtype=torch.int32, device=DEV) if lo >= 32 else
+                                 torch.tensor([hi], dtype=torch.int32, device=DEV), 0, 64)
+    finally:
+        os.environ.pop("MMADA_CHECK_ROWS", None)
+    tiny_model.forward_body(ids)  # the window is cleared by a plain forward
+    assert torch.equal(tiny_model.head_rows(rows, synth.TEXT_VOCAB - 64, synth.TEXT_VOCAB + 448), full)
+    tiny_model.hidden_state()
+
+
+def test_generate_ti2ti_identical_with_and_without_row_window(tiny_model):
+    from mmada_parallel_amd import generate_ti2ti
+
+    job = tiny_job()
+
+    def run():
+        return generate_ti2ti(tiny_model, job["input_ids"].to(DEV), job["text_start"], job["text_end"], job["image_start"],
+                              job["seq_len"], job["newline_every"], text_steps=8, timesteps=4, temperature=0.0,
+                              text_temperature=0.0, cfg_scale=2.0, cfg_img=4.0, uncon_text=job["uncon_text"],
+                              uncon_image=job["uncon_image"], return_state=True)
+
+    a = run()
+    os.environ["MMADA_NO_WINDOW"] = "1"
+    try:
+        b = run()
+    finally:
+        os.environ.pop("MMADA_NO_WINDOW", None)
+    assert torch.equal(a[2], b[2]) and a[1] == b[1]
