@@ -17,7 +17,9 @@ MM_DEVICE void wait_vm_lgkm() {
     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int STAGES, int MINW, bool NOSTORE = false, bool NODMA = false, bool NOLDS = false>
+// SPREAD != 0 (BK = 64 only): the LDS-DMA pieces of the next K-tile are not issued in one burst behind the barrier but
+// one at a time between groups of FN MFMAs (1: during the first 32-deep half, 2: during the second half).
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int MINW, bool NOSTORE = false, bool NODMA = false, bool NOLDS = false, int SPREAD = 0>
 __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var_kernel(GemmArgs g) {
     constexpr int NW = WM * WN;
     constexpr int RB = BK * 2;          // bytes per LDS row
@@ -79,20 +81,42 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var_kernel(GemmArgs g
 
     const int frow = lane & 15, fq = lane >> 4;
     const int nk = g.K / BK;
+    // SPREAD == 3: waves 0..(BM+BN)/64-1 own 64 rows each of the A|W tile for the L2 touch (BK*2 = 128 B = one line/row)
+    const bool pf_wave = SPREAD == 3 && wave < (BM + BN) / 64;
+    const bf16_t* pf_ptr = g.A;
+    float pf_sink = 0.f;
+    if (pf_wave) {
+        const int r = wave * 64 + lane;
+        pf_ptr = r < BM ? g.A + (size_t)min(m0 + r, g.M - 1) * g.lda : g.W + (size_t)min(n0 + r - BM, g.N - 1) * g.ldw;
+    }
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nk) stage(s, s);
 
     for (int kt = 0; kt < nk; ++kt) {
         // tile kt landed for this wave (tiles kt+1 .. kt+STAGES-2 may still be in flight), then everyone's did
-        if (kt + STAGES - 2 < nk)
+        if (SPREAD == 3 && pf_wave && kt >= 1 && kt - 1 + STAGES < nk)
+            wait_vm_lgkm<(STAGES - 2) * (PA + PB) + 1>();  // the newest outstanding op is last iteration's L2 touch
+        else if (kt + STAGES - 2 < nk)
             wait_vm_lgkm<(STAGES - 2) * (PA + PB)>();
         else
             wait_vm_lgkm<0>();
         // NODMA probe: only the first tiles are ever fetched (wrong results; isolates the cost of the global->LDS stream)
-        if (kt + STAGES - 1 < nk && (!NODMA || kt < 2)) stage((kt + STAGES - 1) % STAGES, kt + STAGES - 1);
+        const bool more = kt + STAGES - 1 < nk;
+        if ((SPREAD == 0 || SPREAD == 3) && more && (!NODMA || kt < 2)) stage((kt + STAGES - 1) % STAGES, kt + STAGES - 1);
+        if (SPREAD == 3 && pf_wave && kt + STAGES < nk)  // touch the K-tile after the one being staged: one line per row
+            asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pf_ptr + (size_t)(kt + STAGES) * BK) : "memory");
         const char* At = smem + (kt % STAGES) * STAGE_BYTES;
         const char* Wt = At + A_BYTES;
+        auto piece = [&](int i) {  // i-th LDS-DMA piece of this wave for K-tile kt + STAGES - 1
+            char* base = smem + ((kt + STAGES - 1) % STAGES) * STAGE_BYTES;
+            const int kn = kt + STAGES - 1;
+            if (i < PA)
+                __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + kn * BK), (lptr_t)(base + (wave * PA + i) * 1024), 16, 0, 0);
+            else
+                __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i - PA] + kn * BK),
+                                                 (lptr_t)(base + A_BYTES + (wave * PB + i - PA) * 1024), 16, 0, 0);
+        };
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             bf16x8 a[FM], b[FN];
@@ -107,10 +131,20 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var_kernel(GemmArgs g
                 b[ni] = *(const bf16x8*)(Wt + row * RB + (((kk * 4 + fq) ^ swz(row)) << 4));
             }
 #pragma unroll
-            for (int mi = 0; mi < FM; ++mi)
+            for (int mi = 0; mi < FM; ++mi) {
 #pragma unroll
                 for (int ni = 0; ni < FN; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+                if (SPREAD != 0 && kk == SPREAD - 1) {
+                    // pieces mi, mi + FM, ... of this wave go out in the shadow of the MFMA group just issued
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more) {
+#pragma unroll
+                        for (int i = mi; i < PA + PB; i += FM) piece(i);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
     }
 
@@ -967,11 +1001,11 @@ int launch_big(const GemmArgs& g, hipStream_t s) {
     return 0;
 }
 
-template <int BM, int BN, int BK, int WM, int WN, int STAGES, int MINW, bool NOSTORE = false, bool NODMA = false, bool NOLDS = false>
+template <int BM, int BN, int BK, int WM, int WN, int STAGES, int MINW, bool NOSTORE = false, bool NODMA = false, bool NOLDS = false, int SPREAD = 0>
 int launch_var(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = STAGES * (BM + BN) * BK * 2;
     static bool attr_set = false;
-    auto fn = gemm_var_kernel<BM, BN, BK, WM, WN, STAGES, MINW, NOSTORE, NODMA, NOLDS>;
+    auto fn = gemm_var_kernel<BM, BN, BK, WM, WN, STAGES, MINW, NOSTORE, NODMA, NOLDS, SPREAD>;
     if (!attr_set) {
         MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         attr_set = true;
@@ -1022,6 +1056,9 @@ int launch_gemm_variant(int variant, const GemmArgs& g, hipStream_t s) {
         case 35: return launch_pp2<2>(g, s);
         case 32: return launch_pp<false, 1>(g, s);
         case 33: return launch_pp<false, 2>(g, s);
+        case 70: return launch_var<256, 256, 64, 4, 4, 2, 4, false, false, false, 1>(g, s);  // v10, DMA pieces spread over the first half's MFMAs
+        case 71: return launch_var<256, 256, 64, 4, 4, 2, 4, false, false, false, 2>(g, s);  // ... over the second half's
+        case 72: return launch_var<256, 256, 64, 4, 4, 2, 4, false, false, false, 3>(g, s);  // v10 + L2 touch of the K-tile after next
         case 60: return launch_pers<256, 256, 64, 4, 4, 2, 4, false>(g, s);  // v10, persistent
         case 61: return launch_pers<256, 256, 64, 4, 4, 2, 4, true>(g, s);   // ... + next-tile prefetch under the epilogue
         case 20: return launch_big<4, false>(g, s);
