@@ -163,6 +163,120 @@ __global__ __launch_bounds__(64 * WM * WN, MINW) void gemm_var_kernel(GemmArgs g
         }
 }
 
+// 1.5 K-tiles of look-ahead inside 160 KiB at 256x256: the ring holds FIVE 32-deep half-tiles (5 x 32 KiB); every
+// iteration multiplies two of them (one 64-deep K-tile, one barrier) while three are in flight or landed.
+//   wait(halves 2t, 2t+1 landed; half 2t+2 may be in flight) ; barrier ; issue halves 2t+3, 2t+4 ; multiply
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(64 * WM * WN, 4) void gemm_half_kernel(GemmArgs g) {
+    constexpr int NW = WM * WN, BKH = 32, RB = 64, CPR = 4, RPP = 16, NSLOT = 5;
+    constexpr int A_BYTES = BM * RB, B_BYTES = BN * RB, SLOT_BYTES = A_BYTES + B_BYTES;
+    constexpr int PA = BM / RPP / NW, PB = BN / RPP / NW;
+    constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    static_assert(BM % (RPP * NW) == 0 && BN % (RPP * NW) == 0, "piece split");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+    const int id = xcd_remap(blockIdx.x, gridDim.x);
+    constexpr int GN = 4;
+    const int gsize = GN * ntm;
+    const int grp = id / gsize, rem = id - grp * gsize;
+    const int gn = min(GN, ntn - grp * GN);
+    const int mt = rem / gn, nt = grp * GN + (rem - (rem / gn) * gn);
+    const int m0 = mt * BM, n0 = nt * BN;
+    auto swz = [](int row) { return (row >> 2) & 3; };  // 4 rows of 64 B per 256-B bank row
+    const bf16_t* asrc[PA];
+    const bf16_t* wsrc[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int row = (wave * PA + i) * RPP + lane / CPR;
+        asrc[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + ((lane % CPR) ^ swz(row)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int row = (wave * PB + i) * RPP + lane / CPR;
+        wsrc[i] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw + ((lane % CPR) ^ swz(row)) * 8;
+    }
+    auto issue = [&](int hf) {  // half-tile hf -> slot hf % 5
+        char* base = smem + (hf % NSLOT) * SLOT_BYTES;
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(asrc[i] + hf * BKH), (lptr_t)(base + (wave * PA + i) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            __builtin_amdgcn_global_load_lds((gptr_t)(wsrc[i] + hf * BKH), (lptr_t)(base + A_BYTES + (wave * PB + i) * 1024),
+                                             16, 0, 0);
+    };
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    const int nh = g.K / BKH, nk = nh / 2;
+    issue(0);
+    issue(1);
+    if (nh > 2) issue(2);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (2 * kt + 2 < nh)
+            wait_vm_lgkm<PA + PB>();
+        else
+            wait_vm_lgkm<0>();
+        if (2 * kt + 3 < nh) issue(2 * kt + 3);
+        if (2 * kt + 4 < nh) issue(2 * kt + 4);
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const char* At = smem + ((2 * kt + hh) % NSLOT) * SLOT_BYTES;
+            const char* Wt = At + A_BYTES;
+            bf16x8 a[FM], b[FN];
+#pragma unroll
+            for (int mi = 0; mi < FM; ++mi) {
+                const int row = wm * TM + mi * 16 + frow;
+                a[mi] = *(const bf16x8*)(At + row * RB + ((fq ^ swz(row)) << 4));
+            }
+#pragma unroll
+            for (int ni = 0; ni < FN; ++ni) {
+                const int row = wn * TN + ni * 16 + frow;
+                b[ni] = *(const bf16x8*)(Wt + row * RB + ((fq ^ swz(row)) << 4));
+            }
+#pragma unroll
+            for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < FN; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    const int mrow0 = m0 + wm * TM + fq * 4, ncol0 = n0 + wn * TN + frow;
+#pragma unroll
+    for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = mrow0 + mi * 16 + r;
+            if (m >= g.M) continue;
+#pragma unroll
+            for (int ni = 0; ni < FN; ++ni) {
+                const int n = ncol0 + ni * 16;
+                if (n < g.N) g.C[(size_t)m * g.ldc + n] = f2bf(acc[mi][ni][r]);
+            }
+        }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_half(const GemmArgs& g, hipStream_t s) {
+    constexpr int LDS = 5 * (BM + BN) * 64;
+    static bool attr_set = false;
+    auto fn = gemm_half_kernel<BM, BN, WM, WN>;
+    if (!attr_set) {
+        MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        attr_set = true;
+    }
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+    hipLaunchKernelGGL(fn, dim3(ntm * ntn), dim3(64 * WM * WN), LDS, s, g);
+    MM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
 // Persistent data-parallel form of gemm_var_kernel: one workgroup per CU walks the tile sequence with stride gridDim
 // (same XCD-contiguous, K-lockstep order as the one-tile-per-workgroup launch); with PREFETCH the first STAGES-1
 // K-tiles of the NEXT output tile are requested before the epilogue stores of the current one.
@@ -1059,6 +1173,7 @@ int launch_gemm_variant(int variant, const GemmArgs& g, hipStream_t s) {
         case 70: return launch_var<256, 256, 64, 4, 4, 2, 4, false, false, false, 1>(g, s);  // v10, DMA pieces spread over the first half's MFMAs
         case 71: return launch_var<256, 256, 64, 4, 4, 2, 4, false, false, false, 2>(g, s);  // ... over the second half's
         case 72: return launch_var<256, 256, 64, 4, 4, 2, 4, false, false, false, 3>(g, s);  // v10 + L2 touch of the K-tile after next
+        case 80: return launch_half<256, 256, 4, 4>(g, s);  // five 32-deep half-tiles in flight, one barrier per 64
         case 60: return launch_pers<256, 256, 64, 4, 4, 2, 4, false>(g, s);  // v10, persistent
         case 61: return launch_pers<256, 256, 64, 4, 4, 2, 4, true>(g, s);   // ... + next-tile prefetch under the epilogue
         case 20: return launch_big<4, false>(g, s);
