@@ -77,18 +77,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     float m_run = -1e30f, l_run = 0.f;  // m_run in scaled log2 units
 
     // LDS-DMA sources: wave w moves K pieces 4w..4w+3 (4 rows x 256 B each) and vT pieces 4w..4w+3 (8 rows x 128 B)
-    int koff[4], voff[4];
+    // byte offsets (unsigned 32-bit) from a wave-uniform tile base: the loads take the scalar-base + vector-offset form,
+    // so advancing to the next tile is two scalar adds instead of eight 64-bit vector adds
+    unsigned koff[4], voff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int kr = (wave * 4 + i) * 4 + (lane >> 4);
-        koff[i] = kr * 128 + (((lane & 15) ^ (kr & 15)) << 3);
+        koff[i] = (unsigned)(kr * 128 + (((lane & 15) ^ (kr & 15)) << 3)) * 2u;
         const int d = (wave * 4 + i) * 8 + (lane >> 3);
-        voff[i] = d * a.Lkv + (((lane & 7) ^ ((d >> 1) & 7)) << 3);
+        voff[i] = (unsigned)(d * a.Lkv + (((lane & 7) ^ ((d >> 1) & 7)) << 3)) * 2u;
     }
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * 2 * TILE_BYTES + wave * 4096;
-        const bf16_t* kb = Kp + (size_t)kt * KB * 128;
-        const bf16_t* vb = Vp + kt * KB;
+        const char* kb = (const char*)Kp + (size_t)kt * KB * 256;
+        const char* vb = (const char*)Vp + (size_t)kt * KB * 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_global_load_lds((gptr_t)(kb + koff[i]), (lptr_t)(base + i * 1024), 16, 0, 0);
