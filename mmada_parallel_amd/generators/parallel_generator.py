@@ -64,14 +64,31 @@ def mask_len_schedule(num_vq_tokens: int, text_steps: int, noise_schedule=cosine
     return out
 
 
-def add_gumbel_noise(logits, temperature=1.0, generator=None):
+class TorchRng:
+    """The reference's random draws, call for call, from torch's RNG on the tensors' device (:13-16, :30-33, :297-302).
+    Parity tests pass an object with the same three methods that replays the draws of a recorded reference run."""
+
+    def rand(self, shape, dtype, device, generator):
+        if generator is not None:
+            return torch.rand(shape, dtype=dtype, device=device, generator=generator)
+        return torch.rand(shape, dtype=dtype, device=device)
+
+    def randn(self, shape, dtype, device, generator):
+        if generator is not None:
+            return torch.randn(shape, dtype=dtype, device=device, generator=generator)
+        return torch.randn(shape, dtype=dtype, device=device)
+
+    def multinomial(self, probs2d, generator):
+        if generator is not None:
+            return torch.multinomial(probs2d, 1, generator=generator)
+        return torch.multinomial(probs2d, 1)
+
+
+def add_gumbel_noise(logits, temperature=1.0, generator=None, rng=None):
     """Reference :8-20 verbatim in meaning (bf16 noise, torch RNG) — torch-ROCm plumbing for text_temperature > 0."""
     if temperature == 0:
         return logits
-    if generator is not None:
-        u = torch.rand(logits.shape, dtype=logits.dtype, device=logits.device, generator=generator)
-    else:
-        u = torch.rand_like(logits)
+    u = (rng or TorchRng()).rand(logits.shape, logits.dtype, logits.device, generator)
     g = -torch.log(-torch.log(u + 1e-10) + 1e-10)
     return logits + temperature * g
 
@@ -101,6 +118,7 @@ def _ti2ti_steps(
     text_vocab_size=126356,
     codebook_size=8192,
     image_step_list=None,
+    rng=None,
 ):
     """Generator core shared by generate_ti2ti and generate_ti2ti_stepwise: runs the reference loop and yields
     (step, ids, info) after every step; `info` carries the image step's sampled ids (before re-masking) when one ran.
@@ -112,6 +130,7 @@ def _ti2ti_steps(
         raise NotImplementedError(remasking)  # 'random' is broken in the reference with a generator
     lib, h = model._lib, model._handle
     device = model.device
+    rng = rng or TorchRng()
     ids = input_ids.to(device=device, dtype=torch.long).clone().contiguous()
     B, L = ids.shape
     V = model.vocab
@@ -172,7 +191,7 @@ def _ti2ti_steps(
             noisy = None
             if text_temperature != 0:
                 noisy = add_gumbel_noise(text_logits.view(B, T, V), temperature=text_temperature,
-                                         generator=generator).contiguous()
+                                         generator=generator, rng=rng).contiguous()
             abi.check(lib.mmada_text_select(h, text_logits.data_ptr(), abi.ptr(noisy), B, T, V, V, ids.data_ptr(), L,
                                             text_start, k_dev[step].data_ptr(), scratch.data_ptr(), st),
                       "mmada_text_select")
@@ -205,19 +224,13 @@ def _ti2ti_steps(
             if temperature == 0:
                 sampled, p_sel = argmax, pmax
             else:
-                if generator is not None:
-                    s64 = torch.multinomial(probs, 1, generator=generator)
-                else:
-                    s64 = torch.multinomial(probs, 1)
+                s64 = rng.multinomial(probs, generator)
                 p_sel = torch.gather(probs, -1, s64).view(B, N).contiguous()
                 sampled = s64.view(B, N).to(torch.int32).contiguous()
             ratio = 1.0 * (step + 1) / text_steps
             img_temp = temperature * (1.0 - ratio)
             # randn is drawn even at temperature 0 (reference :30-33, A.2) so the RNG stream advances identically
-            if generator is not None:
-                noise = torch.randn((B, N), dtype=torch.bfloat16, device=device, generator=generator)
-            else:
-                noise = torch.randn((B, N), dtype=torch.bfloat16, device=device)
+            noise = rng.randn((B, N), torch.bfloat16, device, generator)
             abi.check(lib.mmada_image_commit(h, ids.data_ptr(), B, L, pos_map.data_ptr(), N, sampled.data_ptr(),
                                              p_sel.data_ptr(), noise.data_ptr(), float(img_temp),
                                              mlen_dev[step:step + 1].data_ptr(), int(text_vocab_size),
@@ -253,6 +266,7 @@ def generate_ti2ti(
     text_vocab_size=126356,
     codebook_size=8192,
     return_state=False,
+    rng=None,
 ):
     """Joint text+image generation; returns (List[int] vq ids, str | List[int] text) like the reference
     (generators/parallel_generator.py:102-368).
@@ -263,7 +277,7 @@ def generate_ti2ti(
     for _step, ids, info in _ti2ti_steps(model, input_ids, text_start, text_end, image_start, seq_len, newline_every,
                                          text_steps, text_gen_length, text_block_length, timesteps, temperature,
                                          text_temperature, cfg_scale, cfg_img, uncon_text, uncon_image, tokenizer,
-                                         remasking, noise_schedule, generator, text_vocab_size, codebook_size):
+                                         remasking, noise_schedule, generator, text_vocab_size, codebook_size, rng=rng):
         pos_list = info.get("pos_list", pos_list)
 
     # ===== final read-out (reference :346-368) =====

@@ -12,6 +12,7 @@ Fixtures
                      top-8) — model/modeling_xllmx_dimoo.py:41-72 + model/modeling_llada.py:1201-1415
   sampler_traj.npz   generate_ti2ti driven by a STUB model that returns seeded random bf16 logits: the ids the
                      sampler passes to every model call + final outputs — generators/parallel_generator.py:102-368
+  sampler_noisy.npz  the same at temperature 1.0 / text_temperature 0.7 with every draw taken from a seeded CPU generator
   e2e_tiny.npz       generate_ti2ti with the real tiny model at temperature 0: ids at every model call + outputs
   logconf_table.npy  torch.log(p + 1e-10) in bf16 for every non-negative bf16 p (parallel_generator.py:36)
   t2i_traj.npz       generate_image (A text-to-image MaskGIT sampler) driven by the same kind of stub model, with and
@@ -122,7 +123,7 @@ def synthetic_sd():
     return _SD
 
 
-def run_reference_sampler(model, job, **kw):
+def run_reference_sampler(model, job, generator=None, **kw):
     from generators.parallel_generator import generate_ti2ti
 
     rec = Recorder(model)
@@ -130,7 +131,7 @@ def run_reference_sampler(model, job, **kw):
     with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
         vq, text = generate_ti2ti(rec, job["input_ids"], job["text_start"], job["text_end"], job["image_start"],
                                   job["seq_len"], job["newline_every"], uncon_text=job["uncon_text"],
-                                  uncon_image=job["uncon_image"], tokenizer=None, **kw)
+                                  uncon_image=job["uncon_image"], tokenizer=None, generator=generator, **kw)
     return rec.calls, vq, text
 
 
@@ -163,6 +164,32 @@ def gen_sampler_traj():
         out[name + "_seed"] = np.array(seed)
         print(f"sampler_traj[{name}]: {len(calls)} model calls, {len(text)} text tokens")
     np.savez_compressed(os.path.join(OUT, "sampler_traj.npz"), **out)
+
+
+def gen_sampler_noisy():
+    """generate_ti2ti at temperature > 0 (the README's defaults are temperature 1.0 / text_temperature 0.7): stub logits, all
+    random draws from a seeded CPU generator handed to the reference (`generator=`)."""
+    from tests.helpers import NOISY_CASES
+
+    job = tiny_job()
+    V = STUB_TEXT_VOCAB + STUB_CB
+    out = {}
+    for ci, (name, kw) in enumerate(NOISY_CASES.items()):
+        seed = 131 + ci
+
+        def fn(ids, call_idx, seed=seed):
+            return SimpleNamespace(logits=stub_logits(seed, call_idx, ids.shape[0], ids.shape[1], V))
+
+        gen = torch.Generator().manual_seed(500 + ci)
+        calls, vq, text = run_reference_sampler(fn, job, generator=gen, text_vocab_size=STUB_TEXT_VOCAB,
+                                                codebook_size=STUB_CB, **kw)
+        out[name + "_calls"] = torch.cat(calls, 0).numpy()
+        out[name + "_vq"] = np.array(vq, np.int64)
+        out[name + "_text"] = np.array(text, np.int64)
+        out[name + "_seed"] = np.array(seed)
+        out[name + "_gen_seed"] = np.array(500 + ci)
+        print(f"sampler_noisy[{name}]: {len(calls)} model calls, {len(text)} text tokens")
+    np.savez_compressed(os.path.join(OUT, "sampler_noisy.npz"), **out)
 
 
 def gen_e2e():
@@ -556,5 +583,6 @@ if __name__ == "__main__":
     gen_stepwise_traj()
     gen_m_traj()
     gen_sampler_traj()
+    gen_sampler_noisy()
     gen_forward()
     gen_e2e()

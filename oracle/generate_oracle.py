@@ -33,8 +33,11 @@ def generate(model_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.
              image_start: int, seq_len: int, newline_every: int, text_steps: int, timesteps: int,
              cfg_scale: float, cfg_img: float, uncon_text: Optional[torch.Tensor], uncon_image: Optional[torch.Tensor],
              text_vocab_size: int = 126356, codebook_size: int = 8192, trace: Optional[list] = None,
-             image_step_list: Optional[list] = None) -> torch.Tensor:
-    """temperature = text_temperature = 0 path.  Returns the final ids before the random fill (:360-362)."""
+             image_step_list: Optional[list] = None, temperature: float = 0.0, text_temperature: float = 0.0,
+             generator=None) -> torch.Tensor:
+    """Returns the final ids before the random fill (:360-362).  temperature / text_temperature > 0 draw from
+    `generator` (a CPU generator) with the reference's calls in the reference's order: torch.rand for the text Gumbel
+    noise (:13-16), torch.multinomial for the image tokens (:297-302), torch.randn for the re-mask jitter (:30-33)."""
     ids = input_ids.clone()
     assert ids.shape[0] == 1
     image_end = image_start + seq_len + seq_len // newline_every
@@ -55,7 +58,12 @@ def generate(model_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.
     for step in range(text_steps):
         cond = call(ids)  # :177-178
         if int((ids[0, text_start:text_end] == MASK_TOKEN).sum()) > 0:  # :183
-            ids, _, _ = so.text_select(cond[:, text_start:text_end, :], None, ids, text_start, [k_sched[step]])
+            tl = cond[:, text_start:text_end, :].contiguous()
+            noisy = None
+            if text_temperature != 0:  # add_gumbel_noise :8-20 (bf16 tensor ops)
+                u = torch.rand(tl.shape, dtype=tl.dtype, generator=generator)
+                noisy = (tl + text_temperature * (-torch.log(-torch.log(u + 1e-10) + 1e-10))).contiguous()
+            ids, _, _ = so.text_select(tl, noisy, ids, text_start, [k_sched[step]])
         if step in img_steps:  # :220
             cond_vq = cond[:, pos, lo:hi]
             ut = ui = None
@@ -68,10 +76,19 @@ def generate(model_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.
                 ut, ui = call(a)[:, pos, lo:hi], call(b)[:, pos, lo:hi]
             else:
                 ut = ui = torch.zeros_like(cond_vq)
-            am, pm, _ = so.image_probs(cond_vq.contiguous(), ut.contiguous(), ui.contiguous(), cfg_scale, cfg_img)
+            am, pm, probs = so.image_probs(cond_vq.contiguous(), ut.contiguous(), ui.contiguous(), cfg_scale, cfg_img,
+                                           want_probs=temperature != 0)
+            if temperature != 0:  # :297-302, then the probability of the drawn token (:311)
+                s64 = torch.multinomial(probs.reshape(-1, codebook_size), 1, generator=generator)
+                pm = torch.gather(probs.reshape(-1, codebook_size), -1, s64).view(1, seq_len)
+                am = s64.view(1, seq_len).to(torch.int32)
             ratio = 1.0 * (step + 1) / text_steps
             mask_ratio = torch.cos(torch.tensor(ratio) * math.pi / 2)  # cosine_schedule :73-75
             mlen = int((seq_len * mask_ratio).floor().long())  # :321
-            noise = torch.zeros((1, seq_len), dtype=torch.bfloat16)  # temperature 0: 0 * randn
-            ids = so.image_commit(ids, pos, am, pm, noise, 0.0, mlen, MASK_TOKEN, text_vocab_size, codebook_size)
+            if temperature != 0:
+                noise = torch.randn((1, seq_len), dtype=torch.bfloat16, generator=generator)  # :30-33
+            else:
+                noise = torch.zeros((1, seq_len), dtype=torch.bfloat16)  # temperature 0: 0 * randn
+            ids = so.image_commit(ids, pos, am, pm, noise, temperature * (1.0 - ratio), mlen, MASK_TOKEN, text_vocab_size,
+                                  codebook_size)
     return ids

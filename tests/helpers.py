@@ -112,3 +112,24 @@ def m_t2i_job(seed, B, known):
         img[:, :known] = torch.randint(0, sh["CB"], (B, known), generator=g) + sh["text_vocab"]
     tail = torch.cat([torch.full((B, 1), 2040), img, torch.full((B, 1), 2041)], dim=1)
     return torch.cat([prompt, tail], dim=1), torch.cat([unc, tail], dim=1)
+
+
+# generate_ti2ti at temperature > 0 (README default: temperature=1.0, text_temperature=0.7): tests/golden/sampler_noisy.npz
+NOISY_CASES = {
+    "noisy_img": dict(text_steps=8, timesteps=4, temperature=1.0, text_temperature=0.0, cfg_scale=0.0, cfg_img=4.0),
+    "noisy_both": dict(text_steps=6, timesteps=6, temperature=1.0, text_temperature=0.7, cfg_scale=2.0, cfg_img=3.0),
+}
+
+
+class ReplayCpuRng:
+    """Draws exactly what the reference draws when it runs on CPU with a seeded CPU generator (torch.rand / randn in the
+    tensor's dtype, torch.multinomial), then moves the result to the device the HIP path works on."""
+
+    def rand(self, shape, dtype, device, generator):
+        return torch.rand(tuple(shape), dtype=dtype, generator=generator).to(device)
+
+    def randn(self, shape, dtype, device, generator):
+        return torch.randn(tuple(shape), dtype=dtype, generator=generator).to(device)
+
+    def multinomial(self, probs2d, generator):
+        return torch.multinomial(probs2d.cpu(), 1, generator=generator).to(probs2d.device)

@@ -684,3 +684,29 @@ def test_generate_ti2ti_identical_with_and_without_row_window(tiny_model):
     finally:
         os.environ.pop("MMADA_NO_WINDOW", None)
     assert torch.equal(a[2], b[2]) and a[1] == b[1]
+
+
+# ------------------------------------------------------------------ generate_ti2ti at temperature > 0 (README defaults)
+from helpers import NOISY_CASES, ReplayCpuRng  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(NOISY_CASES))
+def test_generate_noisy_stub_trajectory_bit_exact(tiny_model, name):
+    """temperature 1.0 / text_temperature 0.7 (the reference README's defaults): with the reference's torch.rand /
+    torch.multinomial / torch.randn draws replayed from the same seeded CPU generator, the ids of every model call equal
+    the reference's recorded run (tests/golden/sampler_noisy.npz) — Gumbel-noised text argmax, multinomial image tokens
+    and the jittered re-mask all included."""
+    from mmada_parallel_amd import generate_ti2ti
+
+    z = np.load(os.path.join(GOLDEN, "sampler_noisy.npz"))
+    calls_ref = torch.from_numpy(z[name + "_calls"])
+    job, kw = tiny_job(), NOISY_CASES[name]
+    V = STUB_TEXT_VOCAB + STUB_CB
+    stub = _stubbed(tiny_model, int(z[name + "_seed"]), V)
+    gen = torch.Generator().manual_seed(int(z[name + "_gen_seed"]))
+    generate_ti2ti(stub, job["input_ids"].to(DEV), job["text_start"], job["text_end"], job["image_start"], job["seq_len"],
+                   job["newline_every"], uncon_text=job["uncon_text"], uncon_image=job["uncon_image"], tokenizer=None,
+                   text_vocab_size=STUB_TEXT_VOCAB, codebook_size=STUB_CB, generator=gen, rng=ReplayCpuRng(), **kw)
+    got = torch.cat(stub.calls, 0)
+    assert got.shape == calls_ref.shape
+    assert torch.equal(got, calls_ref), f"first differing model call: {(got != calls_ref).any(1).nonzero()[0].item()}"

@@ -340,3 +340,32 @@ def test_m_t2i_trajectory_matches_reference(name):
     assert torch.equal(torch.stack(trace, 0), torch.from_numpy(z[name + "_calls"]))
     assert torch.equal(ids, torch.from_numpy(z[name + "_ids"]))
     assert torch.equal(inp, torch.from_numpy(z[name + "_final_input"]))
+
+
+# ---- generate_ti2ti at temperature > 0 (README defaults), every draw from a seeded CPU generator ---------------------
+from helpers import NOISY_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("name", list(NOISY_CASES))
+def test_noisy_sampler_trajectory_matches_reference(name):
+    z = np.load(os.path.join(GOLDEN, "sampler_noisy.npz"))
+    calls_ref = torch.from_numpy(z[name + "_calls"])
+    seed, job, kw = int(z[name + "_seed"]), tiny_job(), NOISY_CASES[name]
+    V = STUB_TEXT_VOCAB + STUB_CB
+    n = [0]
+
+    def model_fn(ids):
+        n[0] += 1
+        return stub_logits(seed, n[0], ids.shape[0], ids.shape[1], V)
+
+    trace = []
+    gen = torch.Generator().manual_seed(int(z[name + "_gen_seed"]))
+    generate_oracle.generate(model_fn, job["input_ids"], job["text_start"], job["text_end"], job["image_start"],
+                             job["seq_len"], job["newline_every"], text_steps=kw["text_steps"], timesteps=kw["timesteps"],
+                             cfg_scale=kw["cfg_scale"], cfg_img=kw["cfg_img"], uncon_text=job["uncon_text"],
+                             uncon_image=job["uncon_image"], text_vocab_size=STUB_TEXT_VOCAB, codebook_size=STUB_CB,
+                             trace=trace, temperature=kw["temperature"], text_temperature=kw["text_temperature"],
+                             generator=gen)
+    got = torch.cat(trace, 0)
+    assert got.shape == calls_ref.shape
+    assert torch.equal(got, calls_ref), f"first differing model call: {(got != calls_ref).any(1).nonzero()[0].item()}"
