@@ -369,6 +369,8 @@ def gen_vq_decode():
             quant = mv.LFQuantizer(codebook_dim=cfg["z_channels"])
         dec.load_state_dict(sd, strict=True)
         dec.eval()
+        if name == "full":  # the checkpoint contract: key names and shapes of the reference module with default arguments
+            out["full_keys"] = np.array([f"{k}:{tuple(v.shape)}" for k, v in dec.state_dict().items()])
         g = torch.Generator().manual_seed(100 + seed)
         idx = torch.randint(0, 2 ** cfg["z_channels"], (B, hz * hz), generator=g)
         with torch.no_grad():
@@ -390,6 +392,8 @@ def gen_vq_decode():
             quant = mv.LFQuantizer(codebook_dim=cfg["z_channels"])
         enc.load_state_dict(sd, strict=True)
         enc.eval()
+        if name == "full":
+            out["full_keys"] = np.array([f"{k}:{tuple(v.shape)}" for k, v in enc.state_dict().items()])
         img = synth.synthetic_image(B, res, res, seed=200 + seed)
         with torch.no_grad():
             idx = mv.MAGVITv2.get_code(SimpleNamespace(encoder=enc, quantize=quant), img)

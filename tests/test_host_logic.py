@@ -71,3 +71,38 @@ def test_build_ti2ti_sequence():
 def test_prompt_template():
     a, b = generate_text_image_to_text_image_prompt("make it red", "SYS")
     assert a == "<system>SYS</system><user>make it red</user>" and b == "<system>SYS</system><user><uncondition></user>"
+
+
+def test_vq_state_dict_keys_match_the_reference_modules():
+    """Checkpoint contract of the MAGVITv2 path: the key names and shapes the loader expects (synth.vq_*_param_shapes,
+    mirrored by the slot table of csrc/vq_decoder.hip) are those of the reference's VQGANDecoder / VQGANEncoder built with
+    their default arguments (recorded by oracle/gen_golden.py from the reference modules' own state_dict())."""
+    import os
+
+    import numpy as np
+
+    from conftest import GOLDEN
+    from mmada_parallel_amd import synth
+
+    for fixture, shapes in (("vq_decode.npz", synth.vq_decoder_param_shapes(synth.VQ_CFG_M)),
+                            ("vq_encode.npz", synth.vq_encoder_param_shapes(synth.VQ_ENC_CFG_M))):
+        ref = [str(x) for x in np.load(os.path.join(GOLDEN, fixture))["full_keys"]]
+        mine = [f"{k}:{tuple(v)}" for k, v in shapes.items()]
+        assert sorted(ref) == sorted(mine)
+
+
+def test_generate_image_keep_schedule_matches_the_oracle_rule():
+    import torch
+
+    from mmada_parallel_amd.generators.image_generation_generator import keep_schedule
+    from oracle import generate_image_oracle as gio
+
+    for n, steps in ((1024, 18), (256, 7), (16, 5), (3, 4)):
+        want = []
+        for step in range(steps):
+            if step < steps - 1:
+                frac = gio.cosine_schedule(torch.tensor([(step + 1) / steps]))
+                want.append(int((torch.tensor([[n]]).float() * frac).floor().clamp_min(1).long().item()))
+            else:
+                want.append(0)
+        assert keep_schedule(n, steps) == want
