@@ -58,7 +58,7 @@ def job_flops(cfg, L, T, N, text_steps, n_img_steps, V, CB, job=None):
     return total
 
 
-def cpu_baseline(cfg, job, sample_layers=2, reps=2):
+def cpu_baseline(cfg, job, sample_layers=4, reps=2):
     """Oracle (CPU restatement of the reference forward) timed on the host cores on a bounded sample:
     `sample_layers` blocks + consumed LM-head rows at the full shape, extrapolated to 256 forwards / image."""
     from mmada_parallel_amd import synth
