@@ -111,6 +111,7 @@ def generate_image(
         if bool((slots < code_start - 2).any()):
             raise ValueError("masked tokens before code_start - 2 are dropped from the unconditional sequence")
     keep = torch.tensor(keep_schedule(vq_len, timesteps, noise_schedule), dtype=torch.int32, device=device)
+    win = (int(slots[0]), int(slots[-1]) + 1) if N else None   # the only rows ever decoded (one host read, before the loop)
     pos_map = slots.to(torch.int32).contiguous()
     argmax = torch.empty((1, N), dtype=torch.int32, device=device)
     pmax = torch.empty((1, N), dtype=torch.bfloat16, device=device)
@@ -125,13 +126,13 @@ def generate_image(
         rows = slots[masked].to(torch.int32).contiguous()              # flat_idx (:178), ascending positions
         if trace is not None:
             trace.append(x.cpu().clone())
-        model.forward_body(x)
+        model.forward_body(x, consumed=win)
         cond = model.head_rows(rows, off, off + CB)                    # cond_logits[vq_mask] (:130-133) / :155-157
         if use_cfg:
             uncond_ids = torch.cat((uncon_ids, x[:, code_start - 2:]), dim=1).contiguous()   # :123
             if trace is not None:
                 trace.append(uncond_ids.cpu().clone())
-            model.forward_body(uncond_ids)
+            model.forward_body(uncond_ids, consumed=(win[0] - (code_start - 2) + U, win[1] - (code_start - 2) + U))
             urows = (rows - (code_start - 2) + U).contiguous()         # uncond_vq_mask (:124)
             unc = model.head_rows(urows, off, off + CB)
         else:

@@ -134,10 +134,11 @@ def interleave_generate(
         both = torch.cat([ids, unc], dim=0).contiguous()
         if trace is not None:
             trace.append(both.cpu().clone())
-        model.forward_body(both)                                 # one batch-2 forward (:171)
+        is_img = i in img_steps
+        # rows read this step: the text span, plus the image span on image steps (the last block computes only those)
+        model.forward_body(both, consumed=(img_start if is_img else text_start, L))   # one batch-2 forward (:171)
         st = abi.stream_ptr()
         tl = model.head_rows(text_rows, 0, V)                    # [2T, V]: cond rows, uncond rows
-        is_img = i in img_steps
         il = model.head_rows(img_rows, text_vocab, text_vocab + CB) if is_img else None
 
         x0_in = None

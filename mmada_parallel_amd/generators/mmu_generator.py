@@ -69,14 +69,14 @@ def mmu_generate(model, idx=None, input_embeddings=None, max_new_tokens=128, ste
                 both = torch.cat([x, un_x], dim=0).contiguous()
                 if trace is not None:
                     trace.append(both.cpu().clone())
-                model.forward_body(both)
+                model.forward_body(both, consumed=(start, start + BL))   # only the current block is decoded
                 lg = model.head_rows(torch.cat([rows, rows + B * L]), 0, V)   # [2*B*BL, V]: cond rows then uncond rows
                 cond, unc = lg[:B * BL], lg[B * BL:]
                 base, other, scale = unc, cond, float(cfg_scale + 1)          # un + (cfg+1) * (cond - un)  (:666)
             else:
                 if trace is not None:
                     trace.append(x.cpu().clone())
-                model.forward_body(x)
+                model.forward_body(x, consumed=(start, start + BL))
                 cond = model.head_rows(rows, 0, V)
                 base, other, scale = cond, cond, 0.0
             x0_in = None

@@ -77,7 +77,7 @@ def t2i_generate(
             model_input = ids
         if trace is not None:
             trace.append(model_input.cpu().clone())
-        model.forward_body(model_input)
+        model.forward_body(model_input, consumed=(i0, i0 + N))   # only the image span is decoded
         il = model.head_rows(rows, tok_len, tok_len + CB)
         st = abi.stream_ptr()
         il_c, il_u = (il[:B * N], il[B * N:]) if use_cfg else (il, il)

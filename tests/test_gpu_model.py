@@ -408,7 +408,7 @@ def test_m_interleave_stub_trajectory_bit_exact(tiny_model, name):
     stub = _stubbed(tiny_model, seed, V)
     calls = []
 
-    def fb(ids):  # the M sampler runs cond+uncond as ONE batch-2 forward: one stub draw per forward
+    def fb(ids, consumed=None):  # the M sampler runs cond+uncond as ONE batch-2 forward: one stub draw per forward
         stub.n += 1
         calls.append(ids.cpu().clone())
         stub._cur = stub_logits(seed, stub.n, ids.shape[0], ids.shape[1], V).to(DEV)
@@ -541,7 +541,7 @@ def test_mmu_generate_stub_trajectory_bit_exact(tiny_model, name):
     seed, kw, sh = int(z[name + "_seed"]), MMU_CASES[name], MMU_SHAPE
     stub = _stubbed(tiny_model, seed, sh["V"])
 
-    def fb(ids):  # one stub draw per forward, whatever its batch size (like the reference's single model call)
+    def fb(ids, consumed=None):  # one stub draw per forward, whatever its batch size (like the reference's single model call)
         stub.n += 1
         stub.calls.append(ids.cpu().clone())
         stub._cur = stub_logits(seed, stub.n, ids.shape[0], ids.shape[1], sh["V"]).to(DEV)
@@ -588,7 +588,7 @@ def test_m_t2i_generate_stub_trajectory_bit_exact(tiny_model, name):
     inp, unc = m_t2i_job(seed, kw["B"], kw["known"])
     stub = _stubbed(tiny_model, seed, V)
 
-    def fb(ids):
+    def fb(ids, consumed=None):
         stub.n += 1
         stub.calls.append(ids.cpu().clone())
         stub._cur = stub_logits(seed, stub.n, ids.shape[0], ids.shape[1], V).to(DEV)
