@@ -609,7 +609,7 @@ def test_m_t2i_generate_stub_trajectory_bit_exact(tiny_model, name):
 
 
 # ------------------------------------------------------------------ multi-process tensor parallel, end to end (one GPU)
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_multi_rank_tensor_parallel_on_one_gpu(world):
     """bench.py's N-rank path (one process per rank, TP = N, N jobs, micro-batched async all-reduce) launched exactly as
     the driver launches it, except that all ranks share cuda:0 and the collective runs over gloo (MMADA_BENCH_ONE_GPU=1):
