@@ -193,6 +193,23 @@ def main():
         allv = [None] * world
         dist.all_gather_object(allv, final_ids.tolist())  # all B jobs, before the one random fill of the read-out
         ranks_agree = all(a == allv[0] for a in allv) if tp > 1 else None
+    ar_probe = None
+    if use_dist and tp > 1:
+        # outside the timed region: the collective the forward issues 128 times per micro-batch (one micro-batch's residual
+        # stream, bf16), timed alone, so a scaling run also records what the fabric delivered for that message size
+        lane_rows = ((B + 1) // 2) * ((L + 7) // 8 * 8)
+        buf = torch.zeros(lane_rows * cfg["d_model"], dtype=torch.bfloat16, device=dev)
+        for _ in range(3):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            dist.all_reduce(buf)
+        torch.cuda.synchronize()
+        ar_ms = (time.perf_counter() - t1) / 10 * 1e3
+        nbytes = buf.numel() * 2
+        ar_probe = {"bytes": nbytes, "ms": ar_ms, "busbw_GBps": 2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9,
+                    "calls_per_forward": 2 * cfg["n_layers"] * 2}
 
     if rank == 0:
         from mmada_parallel_amd.generators.parallel_generator import image_step_indices
@@ -220,7 +237,7 @@ def main():
                        "text_steps": args.text_steps, "timesteps": args.timesteps, "n_layers": cfg["n_layers"],
                        "algorithmic_pflop_per_image": fl_img / 1e15,
                        "job_mfma_frac": value * fl_img / 1e12 / (world * MFMA_BF16_PEAK_TFLOPS),
-                       "tp_ranks_agree": ranks_agree,
+                       "tp_ranks_agree": ranks_agree, "allreduce_probe": ar_probe,
                        "kernels": kinds},
             "roofline": {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_traffic(KIND_NAMES[dom])},
