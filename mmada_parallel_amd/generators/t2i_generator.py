@@ -21,8 +21,7 @@ from .interleave_generator import TorchRng, _log, cosine_schedule
 from .parallel_generator import mask_len_schedule
 
 
-@torch.no_grad()
-def t2i_generate(
+def _t2i_steps(
     model,
     input_ids: torch.LongTensor = None,
     uncond_input_ids: torch.LongTensor = None,
@@ -42,7 +41,8 @@ def t2i_generate(
     trace: Optional[list] = None,
     **kwargs,
 ):
-    """Returns sampled_ids [B, seq_len] (codebook ids) like the reference; `input_ids` is updated in place."""
+    """Step generator shared by t2i_generate and t2i_generate_decoding_stepwise: yields (step, sampled_ids) right after
+    the draw of every step (where the stepwise variant decodes, :841-848), then commits the step."""
     if not isinstance(model, LLaDAForMultiModalGeneration):
         raise TypeError("t2i_generate (MI355X) needs mmada_parallel_amd.LLaDAForMultiModalGeneration")
     if int(model.config.get("mask_token_id", 126336)) != mask_token_id:
@@ -88,6 +88,7 @@ def t2i_generate(
         cur = ids[:, i0:i0 + N]
         unknown = cur == mask_token_id
         sampled_ids = torch.where(unknown, drawn, cur - tok_len)                   # :322-324
+        yield step, sampled_ids
         ratio = 1.0 * (step + 1) / timesteps
         p_sel = torch.gather(probs.view(B, N, CB), -1, sampled_ids.long()[..., None]).squeeze(-1)
         p_sel = torch.where(unknown, p_sel, torch.finfo(p_sel.dtype).max)          # :334
@@ -99,4 +100,36 @@ def t2i_generate(
                                            tok_len, st), "mmada_image_commit_m")
     if input_ids.data_ptr() != ids.data_ptr():
         input_ids.copy_(ids)                                                       # the reference mutates input_ids (:353)
+
+
+@torch.no_grad()
+def t2i_generate(model, input_ids=None, uncond_input_ids=None, attention_mask=None, uncond_attention_mask=None,
+                 temperature=1.0, timesteps=18, guidance_scale=0, noise_schedule: Callable = cosine_schedule,
+                 generator: torch.Generator = None, config=None, seq_len=1024, mask_token_id=126336, resolution=512,
+                 codebook_size=8192, rng=None, trace: Optional[list] = None, **kwargs):
+    """Returns sampled_ids [B, seq_len] (codebook ids) like the reference (:358); `input_ids` is updated in place."""
+    sampled_ids = None
+    for _step, sampled_ids in _t2i_steps(model, input_ids, uncond_input_ids, attention_mask, uncond_attention_mask,
+                                         temperature, timesteps, guidance_scale, noise_schedule, generator, config, seq_len,
+                                         mask_token_id, resolution, codebook_size, rng, trace, **kwargs):
+        pass
     return sampled_ids
+
+
+@torch.no_grad()
+def t2i_generate_decoding_stepwise(model, input_ids=None, uncond_input_ids=None, attention_mask=None,
+                                   uncond_attention_mask=None, temperature=1.0, timesteps=18, guidance_scale=0,
+                                   noise_schedule: Callable = cosine_schedule, generator: torch.Generator = None, config=None,
+                                   seq_len=1024, mask_token_id=126336, resolution=512, codebook_size=8192, vq_model=None,
+                                   rng=None, **kwargs):
+    """modeling_mmada.py:768-875: t2i_generate that decodes the current samples after every step and yields
+    (PIL image of batch element 0, "Step i/T").  `vq_model` is anything with decode_code (mmada_parallel_amd.MAGVITv2)."""
+    from PIL import Image
+
+    for step, sampled_ids in _t2i_steps(model, input_ids, uncond_input_ids, attention_mask, uncond_attention_mask,
+                                        temperature, timesteps, guidance_scale, noise_schedule, generator, config, seq_len,
+                                        mask_token_id, resolution, codebook_size, rng, None, **kwargs):
+        cur = torch.clamp(sampled_ids.clone(), 0, 8192 - 1)                         # :839-840 (constant as in the reference)
+        images = torch.clamp((vq_model.decode_code(cur) + 1.0) / 2.0, min=0.0, max=1.0) * 255.0
+        images = images.permute(0, 2, 3, 1).cpu().numpy().astype("uint8")
+        yield Image.fromarray(images[0]), f"Step {step + 1}/{timesteps}"

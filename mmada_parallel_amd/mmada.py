@@ -8,6 +8,7 @@ from __future__ import annotations
 from .generators.interleave_generator import interleave_generate as _interleave_generate
 from .generators.mmu_generator import mmu_generate as _mmu_generate, mmu_generate_fast as _mmu_generate_fast
 from .generators.t2i_generator import t2i_generate as _t2i_generate
+from .generators.t2i_generator import t2i_generate_decoding_stepwise as _t2i_stepwise
 from .model import LLaDAForMultiModalGeneration
 
 
@@ -23,6 +24,9 @@ class MMadaModelLM(LLaDAForMultiModalGeneration):
 
     def t2i_generate(self, input_ids=None, uncond_input_ids=None, **kw):          # :264-359
         return _t2i_generate(self, input_ids, uncond_input_ids, **kw)
+
+    def t2i_generate_decoding_stepwise(self, input_ids=None, uncond_input_ids=None, **kw):   # :768-875
+        return _t2i_stepwise(self, input_ids, uncond_input_ids, **kw)
 
     def mmu_generate(self, idx=None, **kw):                                       # :618-692
         return _mmu_generate(self, idx, **kw)

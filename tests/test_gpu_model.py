@@ -710,3 +710,38 @@ def test_generate_noisy_stub_trajectory_bit_exact(tiny_model, name):
     got = torch.cat(stub.calls, 0)
     assert got.shape == calls_ref.shape
     assert torch.equal(got, calls_ref), f"first differing model call: {(got != calls_ref).any(1).nonzero()[0].item()}"
+
+
+def test_m_t2i_stepwise_decodes_every_step_and_matches_t2i_generate(tiny_model):
+    """t2i_generate_decoding_stepwise (modeling_mmada.py:768-875) = t2i_generate + a decode of the current samples after
+    every step: same draws -> same final tokens; one PIL image per step at the decoder's output size."""
+    from types import SimpleNamespace
+
+    from mmada_parallel_amd import MAGVITv2, t2i_generate, t2i_generate_decoding_stepwise
+    from oracle.interleave_oracle import SeededRng
+
+    N, P = 64, 9
+    g = torch.Generator().manual_seed(4)
+    prompt = torch.randint(0, 2000, (1, P), generator=g)
+    tail = torch.cat([torch.full((1, 1), 2040), torch.full((1, N), synth.MASK, dtype=torch.long), torch.full((1, 1), 2041)], 1)
+    inp, unc = torch.cat([prompt, tail], 1), torch.cat([torch.randint(0, 2000, (1, P), generator=g), tail], 1)
+
+    class Tok:
+        def __len__(self):
+            return synth.TEXT_VOCAB
+
+    kw = dict(temperature=1.0, timesteps=4, guidance_scale=2.0, seq_len=N, resolution=6, codebook_size=synth.CODEBOOK,
+              uni_prompting=SimpleNamespace(text_tokenizer=Tok()))
+    a_in = inp.clone()
+    a = t2i_generate(tiny_model, input_ids=a_in, uncond_input_ids=unc.clone(), rng=SeededRng(3), **kw)
+    vq = MAGVITv2.from_state_dict(synth.synthetic_vq_state_dict(synth.VQ_CFG_TINY, 2), synth.VQ_CFG_TINY, device=DEV)
+    b_in = inp.clone()
+    frames = list(t2i_generate_decoding_stepwise(tiny_model, input_ids=b_in, uncond_input_ids=unc.clone(), vq_model=vq,
+                                                 rng=SeededRng(3), **kw))
+    assert [f[1] for f in frames] == [f"Step {i}/4" for i in range(1, 5)]
+    assert all(f[0].size == (16, 16) for f in frames)          # 8x8 codes, 2-level decoder -> 16x16 pixels
+    assert torch.equal(a_in, b_in)                              # same in-place final input_ids
+    last = to_uint8 = None
+    from mmada_parallel_amd.vq import to_uint8_image
+    want = to_uint8_image(vq.decode_code(torch.clamp(a, 0, 8191)))[0].cpu().numpy()
+    assert (np.asarray(frames[-1][0]) == want).all()
