@@ -13,9 +13,8 @@ from __future__ import annotations
 
 import math
 import os
-from typing import List, Optional
+from typing import List
 
-import numpy as np
 import torch
 
 from .. import abi

@@ -6,7 +6,6 @@ against that fixture itself.  Tolerances: one convolution / GroupNorm 1e-5 of th
 different order); the whole 5-level decoder (37 convolutions, 32 GroupNorms) 2e-5 of the output range (measured 5e-6) and at most
 1 level in the final uint8 image.
 """
-import ctypes as C
 import os
 
 import numpy as np
