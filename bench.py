@@ -88,6 +88,48 @@ def cpu_baseline(cfg, job, sample_layers=4, reps=2):
                       f"{per_forward:.2f} s/forward"}
 
 
+class SmiSampler:
+    """Samples `rocm-smi` (sclk, socket power) about once a second in a host thread while the timed region runs; the
+    medians go into the JSON line as evidence of the clock the MFMA peak has to be read against."""
+
+    def __init__(self, device_index):
+        import threading
+
+        self.dev, self.rows, self._stop = device_index, [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import re
+        import subprocess
+
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run(["rocm-smi", "-d", str(self.dev), "--showclocks", "--showpower"], capture_output=True,
+                                     text=True, timeout=10).stdout
+                c = re.search(r"sclk clock level: \S+ \((\d+)Mhz\)", out)
+                p = re.search(r"Power \(W\): ([\d.]+)", out)
+                if c and p:
+                    self.rows.append((int(c.group(1)), float(p.group(1))))
+            except Exception:
+                return
+            self._stop.wait(1.0)
+
+    def __enter__(self):
+        self._t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop.set()
+        self._t.join(timeout=15)
+
+    def summary(self):
+        if not self.rows:
+            return None
+        sc = sorted(r[0] for r in self.rows)
+        pw = sorted(r[1] for r in self.rows)
+        return {"samples": len(self.rows), "sclk_mhz_median": sc[len(sc) // 2], "socket_power_w_median": pw[len(pw) // 2]}
+
+
 def measured_traffic(kernel):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/traffic.json:
     FETCH_SIZE / WRITE_SIZE collected separately, gfx950 correction applied), averaged over the launch mix of one
@@ -177,11 +219,16 @@ def main():
     lib, h = model._lib, model._handle
     barrier()
     abi.check(lib.mmada_profile_begin(h, cfg["n_layers"] // 2), "profile_begin")
+    smi = SmiSampler(local if not one_gpu else 0) if rank == 0 else None
+    if smi:
+        smi.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         vq, _, final_ids = run_once()
     barrier()
     dt = time.perf_counter() - t0
+    if smi:
+        smi.__exit__()
     cnt, ms, fl = (C.c_int32 * 5)(), (C.c_double * 5)(), (C.c_double * 5)()
     abi.check(lib.mmada_profile_end(h, cnt, ms, fl), "profile_end")
     ranks_agree = None
@@ -238,6 +285,7 @@ def main():
                        "algorithmic_pflop_per_image": fl_img / 1e15,
                        "job_mfma_frac": value * fl_img / 1e12 / (world * MFMA_BF16_PEAK_TFLOPS),
                        "tp_ranks_agree": ranks_agree, "allreduce_probe": ar_probe,
+                       "rocm_smi_during_run": smi.summary() if smi else None,
                        "kernels": kinds},
             "roofline": {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_traffic(KIND_NAMES[dom])},
