@@ -77,6 +77,11 @@ struct Tile {
 
 // acc += A[m0.., k-tiles k0..k1) · W[n0.., same k-tiles)^T.  Two LDS stages, one raw s_barrier per K-tile:
 //   wait(tile t landed, my reads of tile t-1 done) ; barrier ; issue tile t+1 ; multiply tile t.
+// Rows of the last row tile that lie beyond M stream from a zero row instead of re-reading row M-1: their products are
+// discarded either way, but MFMAs on zeros switch far less than on live data, and this workload runs at the package
+// power limit — energy not spent there is clock for the rows that count.
+constexpr int ZERO_ROW_ELEMS = 16384;
+
 template <int BM, int WM, int WN>
 MM_DEVICE void mainloop(const GemmArgs& g, char* smem, int m0, int n0, int k0, int k1,
                         f32x4 (&acc)[Tile<BM, WM, WN>::FM][Tile<BM, WM, WN>::FN], int wave, int lane) {
@@ -90,7 +95,7 @@ MM_DEVICE void mainloop(const GemmArgs& g, char* smem, int m0, int n0, int k0, i
         const int piece = min(wave + i * NWAVES, T::PA_TOTAL - 1);
         const int row = piece * 8 + (lane >> 3);
         const int c = (lane & 7) ^ ((row >> 1) & 7);  // logical 16-B chunk this lane fetches
-        asrc[i] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + c * 8;
+        asrc[i] = (m0 + row < g.M || !g.zero_row) ? g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + c * 8 : g.zero_row + c * 8;
     }
 #pragma unroll
     for (int i = 0; i < T::PB; ++i) {
@@ -483,7 +488,26 @@ int launch_t(const GemmArgs& g, hipStream_t s) {
 
 }  // namespace
 
-int launch_gemm(int epi, const GemmArgs& g, hipStream_t s) {
+// one zero row per device (never freed: process lifetime), handed to every launch whose K fits
+static int zero_row_for_device(const bf16_t** out) {
+    static bf16_t* rows[16] = {};
+    static const bool enabled = [] { const char* e = getenv("MMADA_GEMM_ZEROPAD"); return !(e && e[0] == '0'); }();
+    *out = nullptr;
+    if (!enabled) return 0;
+    int dev = 0;
+    MM_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return 0;
+    if (!rows[dev]) {
+        MM_CHECK_HIP(hipMalloc(&rows[dev], ZERO_ROW_ELEMS * sizeof(bf16_t)));
+        MM_CHECK_HIP(hipMemset(rows[dev], 0, ZERO_ROW_ELEMS * sizeof(bf16_t)));
+    }
+    *out = rows[dev];
+    return 0;
+}
+
+int launch_gemm(int epi, const GemmArgs& g_in, hipStream_t s) {
+    GemmArgs g = g_in;
+    if (g.K <= ZERO_ROW_ELEMS && zero_row_for_device(&g.zero_row)) return 1;
     if (g.M <= 0 || g.N <= 0) return 0;
     if (g.K % BK != 0 || g.K <= 0) return mm_fail("gemm: K=%d must be a positive multiple of %d", g.K, BK);
     if ((g.lda % 8) || (g.ldw % 8)) return mm_fail("gemm: lda/ldw must be multiples of 8 elements");

@@ -21,6 +21,8 @@ struct GemmArgs {
     // Row map of the residual read (0 = identity): C/A rows are compact [b*rwin + i], the residual is read from the
     // full-layout row b*rlp + rbeg + i (last block of a forward whose consumer only reads a row window).
     int rwin, rlp, rbeg;
+    // >= K zeros: source of the A rows of the last row tile that lie beyond M (set by launch_gemm; null = re-read row M-1)
+    const bf16_t* zero_row;
     // EPI_QKV: rows are (b, l) with m = b*Lp + l; columns are [q heads | k heads | v heads] x 128
     bf16_t* q;         // [B, Hq , Lkv, 128]
     bf16_t* k;         // [B, Hkv, Lkv, 128]
