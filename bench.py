@@ -176,6 +176,8 @@ def main():
     if use_dist:
         import torch.distributed as dist
 
+        # the collective's kernels must not queue behind a whole round of GEMM workgroups: high-priority RCCL stream
+        os.environ.setdefault("TORCH_NCCL_HIGH_PRIORITY", "1")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         if one_gpu:
