@@ -264,8 +264,6 @@ int mmada_profile_end(mmada_handle* h, int32_t* count_out /*[5]*/, double* ms_ou
 
 /* C[M,N] = A[M,K] · W[N,K]^T, bf16 in / fp32 accumulate / bf16 out (F.linear without bias). */
 int mmada_gemm_bt(const void* A, const void* W, void* C, int M, int N, int K, void* stream);
-/* Same contraction through a numbered tile-shape / pipeline variant (csrc/gemm_var.hip) — tuning sweeps only. */
-int mmada_gemm_variant(int variant, const void* A, const void* W, void* C, int M, int N, int K, void* stream);
 /* RMSLayerNorm.forward (model/modeling_llada.py:301-329): out = w * bf16(x * rsqrt(mean(x²)+eps)). */
 int mmada_rmsnorm(const void* x, const void* w, void* out, int rows, int d, float eps, void* stream);
 /* Unmasked non-causal SDPA over [B,H,L,128] q/k/v (bf16, contiguous) → out [B,L,H*128]

@@ -66,7 +66,6 @@ SIGNATURES = {
     "mmada_profile_begin": (c_int, [c_void_p, c_int]),
     "mmada_profile_end": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "mmada_gemm_bt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
-    "mmada_gemm_variant": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mmada_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "mmada_vq_create": (c_int, [c_void_p, C.POINTER(c_void_p)]),
     "mmada_vq_create_encoder": (c_int, [c_void_p, C.POINTER(c_void_p)]),

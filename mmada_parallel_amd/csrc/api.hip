@@ -406,7 +406,7 @@ int mmada_head_rows(mmada_handle* h, const int32_t* rows, int R, int col_begin, 
     // a windowed forward left the stream compact: row (b, l) sits at b*cur_W + l - cur_beg; rows outside the window the
     // caller declared with mmada_set_consumed_rows were never computed and must not be requested
     if (launch_rmsnorm_gather(h->x, h->ln_f, h->xg, rows, R, h->L, h->cur_W ? h->cur_W : h->Lp, d, h->cfg.rms_eps, s,
-                              h->cur_beg)) return 1;
+                              h->cur_beg, h->B * h->L)) return 1;
     GemmArgs g{};
     g.A = h->xg; g.W = h->lm_head + (size_t)col_begin * d; g.C = (bf16_t*)logits_out;
     g.M = R; g.N = col_end - col_begin; g.K = d;
@@ -518,14 +518,6 @@ int mmada_gemm_bt(const void* A, const void* W, void* C, int M, int N, int K, vo
     g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.C = (bf16_t*)C;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N;
     return launch_gemm(EPI_STORE, g, (hipStream_t)stream);
-}
-
-int mmada_gemm_variant(int variant, const void* A, const void* W, void* C, int M, int N, int K, void* stream) {
-    if (!A || !W || !C) return mm_fail("mmada_gemm_variant: null argument");
-    GemmArgs g{};
-    g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.C = (bf16_t*)C;
-    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N;
-    return launch_gemm_variant(variant, g, (hipStream_t)stream);
 }
 
 int mmada_rmsnorm(const void* x, const void* w, void* out, int rows, int d, float eps, void* stream) {

@@ -102,11 +102,12 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
 
 __global__ __launch_bounds__(256) void rmsnorm_gather_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                              bf16_t* __restrict__ out, const int32_t* __restrict__ rows,
-                                                             int R, int L, int Lp, int d, float eps, int row_off) {
+                                                             int R, int L, int Lp, int d, float eps, int row_off, int nflat) {
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (r >= R) return;
-    const int flat = rows[r];
-    const int b = flat / L, l = flat - b * L - row_off;
+    const int flat = min(max(rows[r], 0), nflat - 1);  // a bad row index must not become an out-of-bounds read
+    const int b = flat / L;
+    const int l = min(max(flat - b * L - row_off, 0), Lp - 1);
     if (d == 4096)
         rmsnorm_row_regs<8>(x + ((size_t)b * Lp + l) * d, w, out + (size_t)r * d, eps, threadIdx.x & 63);
     else
@@ -257,9 +258,10 @@ int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int 
     LAUNCH_CHECK();
 }
 int launch_rmsnorm_gather(const bf16_t* x, const bf16_t* w, bf16_t* out, const int32_t* rows, int R, int L, int Lp, int d,
-                          float eps, hipStream_t s, int row_off) {
+                          float eps, hipStream_t s, int row_off, int nflat) {
     if (R <= 0) return 0;
-    hipLaunchKernelGGL(rmsnorm_gather_kernel, dim3((R + 3) / 4), dim3(256), 0, s, x, w, out, rows, R, L, Lp, d, eps, row_off);
+    if (nflat <= 0) nflat = 0x7fffffff;
+    hipLaunchKernelGGL(rmsnorm_gather_kernel, dim3((R + 3) / 4), dim3(256), 0, s, x, w, out, rows, R, L, Lp, d, eps, row_off, nflat);
     LAUNCH_CHECK();
 }
 int launch_rope_table(float* cos_t, float* sin_t, const float* inv_freq_dev, int max_seq, hipStream_t s) {

@@ -282,83 +282,6 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bt_kernel(GemmArgs g) {
     epilogue<EPI, BM, WM, WN>(g, mt * BM, nt * BN, acc, wave, lane);
 }
 
-// Stream-K launch: a persistent grid of one workgroup per CU; the (tile, K-tile) iteration space is cut into equal
-// contiguous shares, so no CU idles in a partial last wave (M x N = 2438 x 4096 is only 160 tiles of 256 x 256).
-// A tile whose K range is split is finished by the workgroup that holds its k = 0 end: the others publish their
-// fp32 partial accumulators (always the FIRST thing they do, so the owner — which reaches that tile LAST — rarely
-// waits) with an agent-scope release, and the owner adds them in workgroup order (deterministic) after an
-// agent-scope acquire (guide G16).  Flags carry a per-launch epoch: nothing is ever reset.
-struct StreamKArgs {
-    float* partial;        // [grid][16 fragments][1024 threads] x f32x4
-    unsigned* flags;       // [grid]
-    unsigned epoch;
-    int ntm, ntn, nk, units;
-};
-
-template <int EPI>
-__global__ __launch_bounds__(NTHREADS, 4) void gemm_streamk_kernel(GemmArgs g, StreamKArgs sk) {
-    constexpr int BM = 256, WM = 4, WN = 4;
-    using T = Tile<BM, WM, WN>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int G = gridDim.x;
-    const int me = xcd_remap(blockIdx.x, G);  // consecutive shares stay on one XCD
-    auto share_begin = [&](int b) { return (int)(((long long)b * sk.units) / G); };
-    int u = share_begin(me);
-    const int uend = share_begin(me + 1);
-    while (u < uend) {
-        const int t = u / sk.nk, k0 = u - t * sk.nk;
-        const int k1 = min(sk.nk, k0 + (uend - u));
-        int mt, nt;
-        tile_coords(t, sk.ntm, sk.ntn, mt, nt);
-        f32x4 acc[T::FM][T::FN];
-#pragma unroll
-        for (int i = 0; i < T::FM; ++i)
-#pragma unroll
-            for (int j = 0; j < T::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        mainloop<BM, WM, WN>(g, smem, mt * BM, nt * BN, k0, k1, acc, wave, lane);
-        if (k0 != 0) {
-            // not the owner: publish the partial (one per workgroup at most: always its first segment)
-            f32x4* slot = (f32x4*)sk.partial + (size_t)me * (T::FM * T::FN * NTHREADS) + tid;
-#pragma unroll
-            for (int i = 0; i < T::FM; ++i)
-#pragma unroll
-                for (int j = 0; j < T::FN; ++j) slot[(i * T::FN + j) * NTHREADS] = acc[i][j];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) {
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __hip_atomic_store(sk.flags + me, sk.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        } else {
-            if (k1 != sk.nk) {
-                // owner of a split tile: add the partials of the following workgroups, in order
-                const int tile_end = (t + 1) * sk.nk;
-                for (int j = me + 1; j < G && share_begin(j) < tile_end; ++j) {
-                    if (tid == 0) {
-                        unsigned spins = 0;
-                        while (__hip_atomic_load(sk.flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != sk.epoch) {
-                            __builtin_amdgcn_s_sleep(8);
-                            if (++spins > (1u << 24)) break;  // never hang the device: a lost partial shows as a wrong tile
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                    }
-                    __syncthreads();
-                    const f32x4* slot = (const f32x4*)sk.partial + (size_t)j * (T::FM * T::FN * NTHREADS) + tid;
-#pragma unroll
-                    for (int i = 0; i < T::FM; ++i)
-#pragma unroll
-                        for (int jj = 0; jj < T::FN; ++jj) acc[i][jj] += slot[(i * T::FN + jj) * NTHREADS];
-                }
-            }
-            epilogue<EPI, BM, WM, WN>(g, mt * BM, nt * BN, acc, wave, lane);
-        }
-        u += k1 - k0;
-    }
-}
-
 template <int EPI, int BM, int WM, int WN>
 int launch_cfg(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = Tile<BM, WM, WN>::LDS_BYTES;
@@ -386,7 +309,6 @@ int pick_bm(int M, int N, int K) {
         return e ? atoi(e) : 0;
     }();
     if (forced == 128 || forced == 160 || forced == 192 || forced == 224 || forced == 256) return forced;
-    if (M == 0 && N == 0) return 0;  // query: "is a row-tile height forced?" (no)
     const int cand[5] = {256, 224, 192, 160, 128};
     const float h[5] = {1.0f, 1.096f, 1.125f, 1.277f, 1.236f};
     const float A = 0.00549f, C0 = 2.665f, C1 = 0.03107f;
@@ -402,81 +324,8 @@ int pick_bm(int M, int N, int K) {
     return best;
 }
 
-// Library-owned stream-K scratch (one per device): partial accumulators + epoch flags.  All GEMMs of a device
-// are issued on one stream at a time (the forward is a single in-order launch sequence).
-struct StreamKScratch {
-    float* partial = nullptr;
-    unsigned* flags = nullptr;
-    unsigned epoch = 0;
-    int grid = 0;
-};
-
-int streamk_scratch(StreamKScratch** out) {
-    static StreamKScratch per_dev[16];
-    int dev = 0;
-    MM_CHECK_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev >= 16) return mm_fail("gemm: device index %d out of range", dev);
-    StreamKScratch& w = per_dev[dev];
-    if (!w.partial) {
-        hipDeviceProp_t prop;
-        MM_CHECK_HIP(hipGetDeviceProperties(&prop, dev));
-        w.grid = prop.multiProcessorCount;  // one 1024-thread, 128-KiB-LDS workgroup per CU: all co-resident
-        MM_CHECK_HIP(hipMalloc(&w.partial, (size_t)w.grid * 16 * NTHREADS * sizeof(f32x4)));
-        MM_CHECK_HIP(hipMalloc(&w.flags, (size_t)w.grid * sizeof(unsigned)));
-        MM_CHECK_HIP(hipMemset(w.flags, 0, (size_t)w.grid * sizeof(unsigned)));
-    }
-    *out = &w;
-    return 0;
-}
-
-// Measured on MI355X (8B block shapes, M = 2438): stream-K is 15-27 % SLOWER than the data-parallel grid with the
-// row-tile picker (qkv 784 vs 1079 TFLOP/s, attn_out 615 vs 849, gate/up 923 vs 1137, down 842 vs 967).  With one
-// tile per workgroup all 256 CUs walk K in lockstep, so the A/W panels shared by neighbouring tiles are fetched
-// once per XCD L2; stream-K starts every workgroup at a different K offset and loses that sharing.  Kept as an
-// opt-in (MMADA_GEMM_STREAMK=1) for shapes with very few tiles.
-bool streamk_enabled() {
-    static const bool on = [] {
-        const char* e = getenv("MMADA_GEMM_STREAMK");
-        return e && e[0] == '1';
-    }();
-    return on;
-}
-
-template <int EPI>
-int launch_streamk(const GemmArgs& g, hipStream_t s) {
-    StreamKScratch* w;
-    if (streamk_scratch(&w)) return 1;
-    constexpr int LDS = 2 * (256 + BN) * 128;
-    static bool attr_set = false;
-    auto fn = gemm_streamk_kernel<EPI>;
-    if (!attr_set) {
-        MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
-    }
-    StreamKArgs sk;
-    sk.partial = w->partial;
-    sk.flags = w->flags;
-    sk.epoch = ++w->epoch;
-    if (sk.epoch == 0) sk.epoch = ++w->epoch;  // 0 is the "never written" value
-    sk.ntm = (g.M + 255) / 256;
-    sk.ntn = (g.N + BN - 1) / BN;
-    sk.nk = g.K / BK;
-    sk.units = sk.ntm * sk.ntn * sk.nk;
-    hipLaunchKernelGGL(fn, dim3(w->grid), dim3(NTHREADS), LDS, s, g, sk);
-    MM_CHECK_HIP(hipGetLastError());
-    return 0;
-}
-
 template <int EPI>
 int launch_t(const GemmArgs& g, hipStream_t s) {
-    // stream-K when the 256x256 tile grid does not fill whole waves of CUs and there is enough K work to share
-    const int ntiles = ((g.M + 255) / 256) * ((g.N + BN - 1) / BN), nk = g.K / BK;
-    if (streamk_enabled() && pick_bm(0, 0, 0) == 0) {
-        StreamKScratch* w;
-        if (streamk_scratch(&w)) return 1;
-        if (ntiles % w->grid != 0 && ntiles < 8 * w->grid && (long long)ntiles * nk >= 4LL * w->grid)
-            return launch_streamk<EPI>(g, s);
-    }
     switch (pick_bm(g.M, g.N, g.K)) {
         case 256: return launch_cfg<EPI, 256, 4, 4>(g, s);
         case 192: return launch_cfg<EPI, 192, 4, 4>(g, s);

@@ -33,7 +33,6 @@ struct GemmArgs {
 };
 
 int launch_gemm(int epi, const GemmArgs& g, hipStream_t s);
-int launch_gemm_variant(int variant, const GemmArgs& g, hipStream_t s);  // gemm_var.hip
 
 // elementwise.hip
 int launch_embed(const int64_t* ids, const bf16_t* wte, bf16_t* x, int B, int L, int Lp, int d, int vocab, hipStream_t s);
@@ -41,7 +40,7 @@ int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int 
 // gathered rmsnorm: out[r] = rmsnorm(x[map(rows[r])]) where rows[r] = b*L + l and x rows are b*Lp + l
 // x row of the flat index b*L + l is b*row_stride + l - row_off (row_stride = Lp, row_off = 0 for the full layout)
 int launch_rmsnorm_gather(const bf16_t* x, const bf16_t* w, bf16_t* out, const int32_t* rows, int R, int L, int row_stride,
-                          int d, float eps, hipStream_t s, int row_off = 0);
+                          int d, float eps, hipStream_t s, int row_off = 0, int nflat = 0);
 int launch_rope_table(float* cos_t, float* sin_t, const float* inv_freq_dev, int max_seq, hipStream_t s);
 int launch_unpad_rows(const bf16_t* x, bf16_t* out, int B, int L, int Lp, int d, hipStream_t s);
 int launch_iota_rows(int32_t* rows, int n, hipStream_t s);

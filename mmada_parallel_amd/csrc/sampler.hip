@@ -379,6 +379,14 @@ int launch_image_commit(int64_t* ids, int B, int L, const int32_t* pos_map, int 
                         int mask_id, int text_vocab, int codebook, int mvar, hipStream_t s) {
     if (B <= 0 || N <= 0) return 0;
     if (N > 8192) return mm_fail("image_commit: N=%d too large", N);
+    static bool attr_set = false;  // N * 8 B of dynamic LDS + the kernel's static LDS: above the 64 KiB default near N = 8192
+    if (!attr_set) {
+        MM_CHECK_HIP(hipFuncSetAttribute((const void*)image_commit_kernel<true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
+        MM_CHECK_HIP(hipFuncSetAttribute((const void*)image_commit_kernel<false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
+        attr_set = true;
+    }
     if (mvar) {
         if (!noise) return mm_fail("image_commit (M variant): the gumbel tensor is required");
         hipLaunchKernelGGL(image_commit_kernel<true>, dim3(B), dim3(1024), (size_t)N * 8, s, ids, L, pos_map, N, sampled_in,

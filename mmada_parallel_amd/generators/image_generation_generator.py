@@ -151,8 +151,8 @@ def generate_image(
             sampled = (logits / temperature + g).argmax(dim=-1)
             conf = probs[:n_unknown].gather(-1, sampled.unsqueeze(-1)).squeeze(-1)
         # gumbel of mask_by_random_topk is drawn even at temperature 0 (utils/generation_utils.py:57): keep the RNG in step
-        gm = _gumbel(rng.rand((1, n_unknown), torch.bfloat16, device, generator)) if temperature != 0.0 or generator is not None \
-            else None
+        # (always drawn, also with generator=None — the reference's rand_like advances the global RNG either way)
+        gm = _gumbel(rng.rand((1, n_unknown), torch.bfloat16, device, generator))
         # scatter the per-masked-slot results back to slot order for the commit kernel
         s_full = torch.zeros((1, N), dtype=torch.int32, device=device)
         p_full = torch.zeros((1, N), dtype=torch.bfloat16, device=device)

@@ -22,6 +22,13 @@ import torch
 from . import abi
 
 _SUPPORTED = dict(block_type="llama", activation_type="silu", layer_norm_type="rms")
+# what the reference's ModelConfig assumes for a key that is absent from config.json (model/configuration_llada.py:147-317):
+# a trimmed config must be read the way the reference would read it, not silently as the llama/silu/untied layout
+_REFERENCE_DEFAULTS = dict(block_type="sequential", activation_type="swiglu", layer_norm_type="default", rope=False,
+                           rope_full_precision=True, weight_tying=True, include_bias=False, alibi=False,
+                           attention_layer_norm=False, scale_logits=False, input_emb_norm=False, include_qkv_bias=None,
+                           rms_norm_eps=1e-5, rope_theta=10000.0, max_sequence_length=1024, mlp_ratio=4,
+                           multi_query_attention=None, n_kv_heads=None)
 
 
 class CausalLMOutputLite(SimpleNamespace):
@@ -32,20 +39,39 @@ class LLaDAConfigLite(SimpleNamespace):
     def get(self, k, default=None):
         return getattr(self, k, default)
 
+    def ref(self, k):
+        """Value of a ModelConfig field, falling back to the REFERENCE's default when the key is absent."""
+        return getattr(self, k, _REFERENCE_DEFAULTS[k])
+
+
+def effective_n_kv_heads(cfg: LLaDAConfigLite) -> int:
+    """ModelConfig.effective_n_kv_heads (model/configuration_llada.py:366-384)."""
+    n_kv, mqa = cfg.ref("n_kv_heads"), cfg.ref("multi_query_attention")
+    if n_kv is None:
+        return 1 if mqa is True else cfg.n_heads
+    if mqa is None:
+        return n_kv
+    should = 1 if mqa else cfg.n_heads
+    if n_kv != should:
+        raise ValueError("You can't set `multi_query_attention` and `n_kv_heads` at the same time.")
+    return should
+
 
 def _validate(cfg: LLaDAConfigLite) -> None:
     def _name(v):
         return getattr(v, "value", v)
 
     for k, want in _SUPPORTED.items():
-        got = _name(cfg.get(k, want))
-        if got is not None and str(got) != want:
-            raise NotImplementedError(f"config.{k}={got!r}: only {want!r} is on the MI355X hot path")
+        got = _name(cfg.ref(k))
+        if str(got) != want:
+            how = "" if hasattr(cfg, k) else " (the reference's default for a key missing from the config)"
+            raise NotImplementedError(f"config.{k}={got!r}{how}: only {want!r} is on the MI355X hot path")
     for flag in ("alibi", "attention_layer_norm", "scale_logits", "input_emb_norm", "include_bias", "include_qkv_bias"):
-        if cfg.get(flag, False):
+        if cfg.ref(flag):
             raise NotImplementedError(f"config.{flag}=True is not supported on the MI355X hot path")
-    if not cfg.get("rope", True) or not cfg.get("rope_full_precision", True):
-        raise NotImplementedError("rope=True and rope_full_precision=True are required")
+    if not cfg.ref("rope") or not cfg.ref("rope_full_precision"):
+        raise NotImplementedError("rope=True and rope_full_precision=True are required (reference default when the key "
+                                  "is missing: rope=False)")
     if cfg.d_model // cfg.n_heads != 128:
         raise NotImplementedError("head_dim must be 128")
 
@@ -71,18 +97,19 @@ class LLaDAForMultiModalGeneration:
         self._handle = C.c_void_p()
         self._ws = None
         self._ws1 = None
+        self._ws_bytes = [0, 0]  # bytes registered with the library per activation context
         self._handle1 = None
         self._split = None
-        self.n_kv_heads = config.get("n_kv_heads") or config.n_heads
+        self.n_kv_heads = effective_n_kv_heads(config)
         self.vocab = config.get("embedding_size") or config.vocab_size
-        self.mlp_hidden = config.get("mlp_hidden_size") or config.get("mlp_ratio", 4) * config.d_model
-        self.max_seq = max_seq or config.get("max_sequence_length", 4096)
+        self.mlp_hidden = config.get("mlp_hidden_size") or config.ref("mlp_ratio") * config.d_model
+        self.max_seq = max_seq or max(int(config.ref("max_sequence_length")), 4096)
         self.max_batch = max_batch
 
         c = abi.MmadaCfg(
             d_model=config.d_model, n_layers=config.n_layers, n_heads=config.n_heads, n_kv_heads=self.n_kv_heads,
             head_dim=128, mlp_hidden=self.mlp_hidden, vocab=self.vocab, max_seq=self.max_seq,
-            rms_eps=float(config.get("rms_norm_eps", 1e-5)), rope_theta=float(config.get("rope_theta", 10000.0)),
+            rms_eps=float(config.ref("rms_norm_eps")), rope_theta=float(config.ref("rope_theta")),
             tp_rank=tp_rank, tp_size=tp_size, mask_token_id=int(config.get("mask_token_id", self.MASK_TOKEN)),
             text_vocab_size=int(config.get("text_vocab_size", 126356)),
             codebook_size=int(config.get("codebook_size", 8192)), reserved=0)
@@ -105,7 +132,7 @@ class LLaDAForMultiModalGeneration:
 
         self._wte = get(p + "wte.weight")
         self._ln_f = get(p + "ln_f.weight")
-        self._head = self._wte if self.config.get("weight_tying", False) else get(p + "ff_out.weight")
+        self._head = self._wte if self.config.ref("weight_tying") else get(p + "ff_out.weight")
         abi.check(self._lib.mmada_bind_globals(self._handle, self._wte.data_ptr(), self._ln_f.data_ptr(),
                                                self._head.data_ptr()), "mmada_bind_globals")
         st = abi.stream_ptr()
@@ -156,12 +183,12 @@ class LLaDAForMultiModalGeneration:
     def _ensure_ws(self, B: int, L: int, lane: int = 0) -> None:
         h = self._lane_handle(lane)
         need = self._lib.mmada_workspace_bytes(h, B, L)
-        ws = self._ws if lane == 0 else self._ws1
-        if ws is None or ws.numel() < need:
+        if need > self._ws_bytes[lane]:  # compare with what the LIBRARY was given, not with the padded tensor
             grow = max(need, self._lib.mmada_workspace_bytes(h, max(B, self.max_batch), L))
             ws = torch.empty(grow + 256, dtype=torch.uint8, device=self.device)
             base = (ws.data_ptr() + 255) // 256 * 256
             abi.check(self._lib.mmada_set_workspace(h, base, grow), "mmada_set_workspace")
+            self._ws_bytes[lane] = grow
             if lane == 0:
                 self._ws = ws
             else:
@@ -306,8 +333,9 @@ class LLaDAForMultiModalGeneration:
     def forward(self, input_ids=None, labels=None, infer=False, use_cache=False, **_):
         if not infer or labels is not None:
             raise NotImplementedError("only forward(infer=True) is on the MI355X hot path (training loss is out of scope)")
-        if use_cache:
-            raise NotImplementedError("use_cache=True (dLLM cache) is not on the TI2TI path")
+        # use_cache: the reference wrapper forwards only the flag, never a `to_compute_mask`
+        # (model/modeling_xllmx_dimoo.py:41-72), so the blocks merely keep references to this call's k/v and logits
+        # (model/modeling_llada.py:929-940, 1406-1413) — every row is recomputed and the logits are unchanged.
         self.forward_body(input_ids)
         B, L = self._shape
         rows = torch.arange(B * L, dtype=torch.int32, device=self.device)
@@ -315,6 +343,16 @@ class LLaDAForMultiModalGeneration:
         return CausalLMOutputLite(logits=logits)
 
     __call__ = forward
+
+    def caching(self, enable: bool = True):
+        """LLaDAModelLM.caching (model/modeling_llada.py:1417-1421, 1560-1561): switches the dLLM cache bookkeeping on or
+        off and clears it.  Callers of this model never hand it a compute mask, so the switch has no arithmetic effect; it
+        exists so the reference's own `generate_image` (generators/image_generation_generator.py:65-68) runs on this
+        class unmodified."""
+        self.use_cache = bool(enable)
+
+    def empty_cache(self):
+        """LLaDAModelLM.empty_cache (model/modeling_llada.py:1423-1426, 1563-1564): drops cached k/v/logits (none kept)."""
 
     def eval(self):
         return self

@@ -3,12 +3,21 @@ csrc/elementwise.hip pack_qkv/pack_gate_up/pack_cols) as plain index arithmetic,
 
 Megatron-style: q/k/v and ff_proj/up_proj are column-parallel (output-feature slices: whole heads / MLP columns),
 attn_out and ff_out are row-parallel (input-feature slices).  Each rank produces a partial sum of the two
-row-parallel outputs; rank 0 additionally adds the residual, so  all_reduce(sum)  of the per-rank buffers IS the new
-residual stream (reference block: model/modeling_llada.py:906-972).
+row-parallel outputs, rounded to bf16; the residual of row m is added by exactly one rank — its owner
+`residual_owner(m, size)` = (m >> 4) % size, i.e. ownership rotates over the ranks in 16-row groups so every rank reads
+1/size of the residual stream (csrc/gemm.hip EPI_RESID, GemmArgs::resid_mod/resid_rank) — so the sum over ranks of the
+per-rank buffers IS the new residual stream (reference block: model/modeling_llada.py:906-972).
+Because every rank rounds its partial to bf16 before the sum, TP=k results differ from TP=1 by bf16 rounding of the
+partials (not bit-identical; the tolerance is stated in INTEGRATION.md and asserted in tests/test_gpu_model.py).
 """
 from __future__ import annotations
 
 from typing import Dict, Tuple
+
+
+def residual_owner(row: int, size: int) -> int:
+    """Rank whose row-parallel GEMM epilogue adds the residual of stream row `row` (16-row groups, round robin)."""
+    return (row >> 4) % size
 
 
 def head_range(n_heads: int, rank: int, size: int) -> Tuple[int, int]:

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Time the GEMM tile/pipeline variants (csrc/gemm_var.hip) on the four projection shapes of the 8B block.
+"""Time the GEMM tile/pipeline variants (tools/tune/gemm_var.hip, built into tools/libmmada_tune.so) on the four projection shapes of the 8B block.
 
     python tools/gemm_sweep.py [--variants 0,1,2] [--m 2438,4876]
 Random bf16 operands (zero-filled operands clock ~20 % higher: never bench on zeros).  Interleaved rounds, median.
@@ -11,7 +11,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from mmada_parallel_amd import abi  # noqa: E402
+from tools.tune.build_tune import build as build_tune  # noqa: E402
 
 SHAPES = {"qkv": (12288, 4096), "o": (4096, 4096), "gateup": (24576, 4096), "down": (4096, 12288)}
 
@@ -30,7 +30,10 @@ def main():
     shapes = SHAPES
     if args.shapes:
         shapes = {n: (int(a), int(b)) for n, a, b in (x.split(":") for x in args.shapes.split(","))}
-    lib = abi.lib()
+    import ctypes
+
+    lib = ctypes.CDLL(build_tune())
+    lib.mmada_gemm_variant.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
     dev = "cuda:0"
     variants = [int(v) for v in args.variants.split(",")]
     st = torch.cuda.current_stream().cuda_stream
