@@ -1,14 +1,20 @@
 #!/usr/bin/env python
-"""Headline benchmark: images/sec of the MMaDA-Parallel-A 8B parallel text+image sampler on MI355X.
+"""Headline benchmark: images/sec of the MMaDA-Parallel 8B parallel text+image sampler on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus 1 --steps K --warmup W [--config {1,3,4}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-One "step" = one complete TI2TI job of BASELINE.json configs[1]: 512x512 output, text_steps=128, timesteps=64,
-cfg_scale=0, cfg_img=4.0, temperature=0, batch 1 per tensor-parallel group, L = 2438 tokens, 256 forwards of the 8B
-denoiser (128 conditional + 64 x 2 unconditional), synthetic weights / tokens (no checkpoint offline).
-With N GPUs the model is tensor-parallel over N ranks (RCCL all-reduce over xGMI) and the batch is N jobs (weak
-scaling, BASELINE configs[2]).  Rank 0 prints ONE JSON line.
+--config 1 (default, the headline): one "step" = one complete TI2TI job of BASELINE.json configs[1]: MMaDA-Parallel-A,
+  512x512 output, text_steps=128, timesteps=64, cfg_scale=0, cfg_img=4.0, temperature=0, L = 2438 tokens, 256 forwards
+  of the 8B denoiser (128 conditional + 64 x 2 unconditional).  With N GPUs the model is tensor-parallel over N ranks and
+  the batch is N jobs (weak scaling, BASELINE configs[2]).
+--config 3: BASELINE configs[3] in its single-GPU form: MMaDA-Parallel-M (MAGVITv2 tokenizer), a batch of 4 edit jobs,
+  each pixels in -> pixels out: MAGVITv2.get_code -> interleave_generate (text_steps 128, image_steps 30, text_cfg 2.5,
+  image_cfg 4.0: 128 batch-2 forwards at L = 2349) -> decode_code.  One "step" = the 4 jobs.
+--config 4: BASELINE configs[4] in its single-GPU form: MMaDA-Parallel-A editing, ONE batch of 16 jobs through
+  generate_ti2ti with cfg_scale=3.0 and cfg_img=4.0 (all three CFG branches contribute), L = 2438: batch-16 conditional
+  and batch-32 unconditional forwards.  One "step" = the 16 jobs.
+Synthetic weights / tokens / pixels (no checkpoint offline).  Rank 0 prints ONE JSON line.
 """
 import argparse
 import ctypes as C
@@ -44,7 +50,7 @@ def last_block_saving(cfg, L, lo, hi):
 
 
 def job_flops(cfg, L, T, N, text_steps, n_img_steps, V, CB, job=None):
-    """FLOPs of one image actually required: LM head on the consumed rows/columns only and, when `job`
+    """FLOPs of one A image actually required: LM head on the consumed rows/columns only and, when `job`
     is given, the last block on the consumed rows only — skipped work is not counted as achieved."""
     fb = body_flops(cfg, L)
     head_text = 2.0 * T * cfg["d_model"] * V
@@ -58,34 +64,73 @@ def job_flops(cfg, L, T, N, text_steps, n_img_steps, V, CB, job=None):
     return total
 
 
-def cpu_baseline(cfg, job, sample_layers=4, reps=2):
-    """Oracle (CPU restatement of the reference forward) timed on the host cores on a bounded sample:
-    `sample_layers` blocks + consumed LM-head rows at the full shape, extrapolated to 256 forwards / image."""
+def m_job_flops(cfg, L, T, N, text_steps, n_img_steps, V, CB, img_start, text_start, windowed=True):
+    """FLOPs of one M edit (interleave_generate): every step is ONE batch-2 forward (cond + uncond); text head on the
+    2T text rows every step, image head on the 2N image rows of image steps; last block on the consumed window."""
+    fb = body_flops(cfg, L)
+    per_seq = text_steps * fb
+    if windowed:
+        per_seq -= (text_steps - n_img_steps) * last_block_saving(cfg, L, text_start, L)
+        per_seq -= n_img_steps * last_block_saving(cfg, L, img_start, L)
+    heads = text_steps * 2 * (2.0 * T * cfg["d_model"] * V) + n_img_steps * 2 * (2.0 * N * cfg["d_model"] * CB)
+    return 2 * per_seq + heads
+
+
+def cpu_baseline(cfg, ids, text_rows, img_rows, seq_forwards, text_heads, img_heads, sample_layers=4, reps=2):
+    """Oracle (CPU restatement of the reference forward, same torch ops as the reference model) timed on THIS box's host
+    cores on a bounded sample — `sample_layers` blocks + the consumed LM-head rows at the full shape — and extrapolated
+    to the `seq_forwards` sequence-forwards (+ head calls) of one image.  The thread count is probed (the fastest of a few
+    candidates on one block: every hyper-thread is NOT the fastest on a 2-socket box), and the unmodified reference's
+    own number, measured where the reference tree exists (tools/cpu_reference_baseline.py), is attached."""
     from mmada_parallel_amd import synth
     from oracle import llada_oracle
 
     small = dict(cfg, n_layers=sample_layers)
     sd = synth.synthetic_state_dict(small, seed=0, device="cpu")
-    ids = job["input_ids"]
     L = ids.shape[1]
-    T, N = job["text_end"] - job["text_start"], job["seq_len"]
-    t_layers, t_head = [], []
+    ncpu = os.cpu_count() or 8
+    probe = dict(cfg, n_layers=1)
+    best_t, best_n = None, None
+    for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64, ncpu // 2, ncpu) if c >= 1}):
+        torch.set_num_threads(n)
+        llada_oracle.forward_hidden(sd, probe, ids)  # warm
+        t0 = time.perf_counter()
+        llada_oracle.forward_hidden(sd, probe, ids)
+        dt = time.perf_counter() - t0
+        if best_t is None or dt < best_t:
+            best_t, best_n = dt, n
+    torch.set_num_threads(best_n)
+    t_layers, t_text, t_img = [], [], []
     for _ in range(reps):
         t0 = time.perf_counter()
         x = llada_oracle.forward_hidden(sd, small, ids)
         t1 = time.perf_counter()
-        llada_oracle.head(sd, small, x[:, job["text_start"]:job["text_end"]])
-        llada_oracle.head(sd, small, x[:, :N], synth.TEXT_VOCAB, synth.TEXT_VOCAB + synth.CODEBOOK)
+        llada_oracle.head(sd, small, x[:, text_rows[0]:text_rows[1]])
         t2 = time.perf_counter()
+        llada_oracle.head(sd, small, x[:, img_rows[0]:img_rows[1]], synth.TEXT_VOCAB, synth.TEXT_VOCAB + synth.CODEBOOK)
+        t3 = time.perf_counter()
         t_layers.append((t1 - t0) / sample_layers)
-        t_head.append(t2 - t1)
+        t_text.append(t2 - t1)
+        t_img.append(t3 - t2)
     per_forward = min(t_layers) * cfg["n_layers"]
-    n_fwd = 128 + 2 * 64
-    per_image = n_fwd * per_forward + 128 * min(t_head)
-    return {"value": 1.0 / per_image, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/llada_oracle.py forward of {sample_layers} of {cfg['n_layers']} blocks + consumed LM-head "
-                      f"rows at L={L} (best of {reps}), extrapolated to {n_fwd} forwards/image: "
-                      f"{per_forward:.2f} s/forward"}
+    per_image = seq_forwards * per_forward + text_heads * min(t_text) + img_heads * min(t_img)
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        flags = ""
+    out = {"value": 1.0 / per_image, "unit": "images/sec", "cores": best_n, "kind": "port",
+           "threads_probed": "fastest of {8,16,32,64,ncpu/2,ncpu} on one block", "logical_cpus": ncpu,
+           "amx_bf16": "amx_bf16" in flags, "avx512_bf16": "avx512_bf16" in flags,
+           "seconds_per_sequence_forward": per_forward,
+           "sample": f"oracle/llada_oracle.py forward of {sample_layers} of {cfg['n_layers']} blocks + consumed LM-head "
+                     f"rows at L={L} (best of {reps}), extrapolated to {seq_forwards} sequence-forwards/image: "
+                     f"{per_forward:.2f} s/forward on {best_n} threads"}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_cpu_reference.json")) as f:
+            out["unmodified_reference_in_build_container"] = json.load(f)
+    except Exception:
+        pass
+    return out
 
 
 class SmiSampler:
@@ -145,19 +190,135 @@ def measured_traffic(kernel):
         return None
 
 
+def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
+    """Returns a dict describing one benchmark step for BASELINE configs[cfgnum]: run(), images per step, FLOPs per image,
+    the strings of the JSON line, and what the CPU baseline has to extrapolate to."""
+    from mmada_parallel_amd import synth
+    from mmada_parallel_amd.generators.parallel_generator import image_step_indices
+
+    full = synth.full_config(cfg)
+    windowed = os.environ.get("MMADA_NO_WINDOW") != "1"
+    V, CB = cfg["embedding_size"], synth.CODEBOOK
+    if cfgnum in (1, 4):
+        from mmada_parallel_amd import LLaDAForMultiModalGeneration, generate_ti2ti
+
+        B = (tp if cfgnum == 1 else 16) if args.batch is None else args.batch
+        cfg_scale = 0.0 if cfgnum == 1 else 3.0
+        sd = synth.synthetic_state_dict(cfg, seed=0, device=str(dev))
+        model = LLaDAForMultiModalGeneration.from_state_dict(full, sd, device=dev, tp_rank=rank if tp > 1 else 0,
+                                                             tp_size=tp, max_batch=2 * B)
+        del sd
+        torch.cuda.empty_cache()
+        job = synth.synthetic_job(512, 512, text_gen_length=256, prompt_len=64, uncond_prompt_len=24, seed=1)
+        ids = job["input_ids"].repeat(B, 1).to(dev)
+        L = ids.shape[1]
+        T, N = job["text_end"] - job["text_start"], job["seq_len"]
+        state = {}
+
+        def run():
+            vq, _, final = generate_ti2ti(model, ids, job["text_start"], job["text_end"], job["image_start"],
+                                          job["seq_len"], job["newline_every"], text_steps=args.text_steps,
+                                          timesteps=args.timesteps, temperature=0.0, text_temperature=0.0,
+                                          cfg_scale=cfg_scale, cfg_img=4.0, uncon_text=job["uncon_text"],
+                                          uncon_image=job["uncon_image"], return_state=True)
+            state["final"] = final
+            return final
+
+        n_img = len(set(image_step_indices(args.text_steps, args.timesteps)))
+        fl = job_flops(cfg, L, T, N, args.text_steps, n_img, V, CB, job if windowed else None)
+        name = ("BASELINE configs[1]: MMaDA-Parallel-A 8B, 512x512, timesteps=64, text_steps=128, cfg_img=4.0, "
+                "temperature=0, L=2438, 256 forwards/image") if cfgnum == 1 else \
+               (f"BASELINE configs[4] (single-GPU form): MMaDA-Parallel-A 8B editing, batch={B}, 512x512, cfg_scale=3.0 + "
+                "cfg_img=4.0 (triple-branch CFG), timesteps=64, text_steps=128, temperature=0, L=2438, 256 sequence-forwards/image")
+        metric = "images/sec (512x512, 64 img + 128 text steps) MMaDA-Parallel-A 8B" + \
+                 ("" if cfgnum == 1 else ", editing mode, cfg_scale=3 + cfg_img=4")
+        return dict(model=model, run=run, images_per_step=B, flops_per_image=fl, workload=name, metric=metric, L=L,
+                    state=state, cpu=dict(ids=job["input_ids"], text_rows=(job["text_start"], job["text_end"]),
+                                          img_rows=(job["image_start"], job["image_start"] + N),
+                                          seq_forwards=args.text_steps + 2 * n_img, text_heads=args.text_steps, img_heads=3 * n_img))
+    if cfgnum == 3:
+        from types import SimpleNamespace
+
+        from mmada_parallel_amd import MAGVITv2, MMadaModelLM
+        from mmada_parallel_amd.vq import to_uint8_image
+
+        jobs = 4 if args.batch is None else args.batch
+        sd = synth.synthetic_state_dict(cfg, seed=0, device=str(dev))
+        model = MMadaModelLM.from_state_dict(full, sd, device=dev, tp_rank=rank if tp > 1 else 0, tp_size=tp, max_batch=2)
+        del sd
+        torch.cuda.empty_cache()
+        vsd = {"encoder." + k: v for k, v in synth.synthetic_vq_state_dict(synth.VQ_ENC_CFG_M, 1).items()}
+        vsd.update({"decoder." + k: v for k, v in synth.synthetic_vq_state_dict(synth.VQ_CFG_M, 2).items()})
+        vq = MAGVITv2(vsd, device=dev)
+        text_vocab = synth.TEXT_VOCAB
+
+        class Tok:
+            bos_token_id = 126080
+
+            def __len__(self):
+                return text_vocab
+
+        N, T = 1024, 256
+        cfgobj = SimpleNamespace(model=SimpleNamespace(mmada=SimpleNamespace(num_vq_tokens=N, codebook_size=CB)),
+                                 dataset=SimpleNamespace(preprocessing=SimpleNamespace(max_seq_length=T)))
+        imgs = synth.synthetic_image(jobs, 512, 512, seed=5).to(dev)
+        g = torch.Generator().manual_seed(3)
+        texts = [torch.randint(0, 100000, (40,), generator=g).to(dev) for _ in range(jobs)]
+        un_texts = [torch.randint(0, 100000, (40,), generator=g).to(dev) for _ in range(jobs)]
+        head = torch.tensor([126340, 126084], device=dev)  # <|interleave|>, <|soi|> stand-ins (M/inference.py:1-14)
+        eoi = torch.tensor([126085], device=dev)
+        P = 2 + N + 1 + 40
+        L = P + 1 + N + 1 + T
+        image_steps = 30 if args.timesteps == 64 else args.timesteps
+        state = {}
+
+        def run():
+            outs = []
+            for j in range(jobs):  # the reference's interleave_generate takes ONE prompt (1-D ids): jobs run one after another
+                tokens = vq.get_code(imgs[j:j + 1]) + text_vocab                              # M/inference.py:79
+                inp = torch.cat([head, tokens[0], eoi, texts[j]])
+                unc = torch.cat([head, torch.zeros_like(tokens[0]), eoi, un_texts[j]])
+                out_img, out_text = model.interleave_generate(
+                    inp, unc, text_cfg=2.5, image_cfg=4.0, text_steps=args.text_steps, image_steps=image_steps,
+                    config=cfgobj, reserved_token_mapping={"<|soi|>": 126084, "<|eoi|>": 126085},
+                    uni_prompting=SimpleNamespace(text_tokenizer=Tok()))
+                outs.append(to_uint8_image(vq.decode_code(out_img)))                          # M/inference.py:127
+            state["final"] = torch.cat([o.reshape(1, -1) for o in outs], 0)
+            return state["final"]
+
+        n_img = len(set(torch.linspace(args.text_steps // 4, args.text_steps - 1, image_steps).round().int().tolist()))
+        fl = m_job_flops(cfg, L, T, N, args.text_steps, n_img, V, CB, P + 1, L - T, windowed)
+        name = (f"BASELINE configs[3] (single-GPU form): MMaDA-Parallel-M 8B (MAGVITv2 tokenizer), batch={jobs} edit jobs run "
+                f"one after another, 512x512 pixels in -> pixels out (get_code, interleave_generate text_steps=128 "
+                f"image_steps=30 text_cfg=2.5 image_cfg=4.0: 128 batch-2 forwards at L={L}, decode_code)")
+        ids1 = torch.zeros((1, L), dtype=torch.long)
+        return dict(model=model, run=run, images_per_step=jobs, flops_per_image=fl, workload=name, L=L, state=state,
+                    metric="images/sec (512x512 edit, 30 img + 128 text steps) MMaDA-Parallel-M 8B",
+                    cpu=dict(ids=ids1, text_rows=(L - T, L), img_rows=(P + 1, P + 1 + N), seq_forwards=2 * args.text_steps,
+                             text_heads=2 * args.text_steps, img_heads=2 * n_img))
+    raise SystemExit(f"--config {cfgnum}: only 1 (headline), 3 (M, batch 4) and 4 (A editing, batch 16) have a single-node form")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", type=int, default=1, choices=[1, 3, 4],
+                    help="index into BASELINE.json configs (1 = the headline, the default the driver runs)")
+    ap.add_argument("--batch", type=int, default=None, help="debug only: jobs per step (marks the line reduced)")
     ap.add_argument("--text-steps", type=int, default=128, help="debug only: any other value marks the line reduced")
     ap.add_argument("--timesteps", type=int, default=64, help="debug only")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (marks the line reduced)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="hipGraph replay of the denoise step (see generators/graph_step.py); auto = MMADA_GRAPH env or off")
     ap.add_argument("--parallelism", choices=["tp", "dp"], default="tp",
                     help="tp (default, BASELINE configs[2]): the model is tensor-parallel over all ranks, batch = N jobs; "
                          "dp: every rank holds the full 16 GB model and runs its own job, no data-path collective")
     args = ap.parse_args()
+    if args.graph != "auto":
+        os.environ["MMADA_GRAPH"] = "1" if args.graph == "on" else "0"
 
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -185,31 +346,16 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    from mmada_parallel_amd import LLaDAForMultiModalGeneration, abi, generate_ti2ti, synth
+    from mmada_parallel_amd import abi, synth
 
     cfg = dict(synth.CFG_8B)
     if args.layers:
         cfg["n_layers"] = args.layers
-    reduced = args.text_steps != 128 or args.timesteps != 64 or args.layers is not None or one_gpu
-    full = synth.full_config(cfg)
+    reduced = (args.text_steps != 128 or args.timesteps != 64 or args.layers is not None or one_gpu
+               or args.batch is not None)
     tp = world if args.parallelism == "tp" else 1
-    B = tp  # weak scaling: one job per rank-equivalent; tp: model sharded over all ranks, dp: replicas
-    sd = synth.synthetic_state_dict(cfg, seed=0, device=str(dev))
-    model = LLaDAForMultiModalGeneration.from_state_dict(full, sd, device=dev, tp_rank=rank if tp > 1 else 0, tp_size=tp,
-                                                         max_batch=2 * B)
-    del sd
-    torch.cuda.empty_cache()
-
-    job = synth.synthetic_job(512, 512, text_gen_length=256, prompt_len=64, uncond_prompt_len=24, seed=1)
-    ids = job["input_ids"].repeat(B, 1).to(dev)
-    L = ids.shape[1]
-    T, N = job["text_end"] - job["text_start"], job["seq_len"]
-
-    def run_once():
-        return generate_ti2ti(model, ids, job["text_start"], job["text_end"], job["image_start"], job["seq_len"],
-                              job["newline_every"], text_steps=args.text_steps, timesteps=args.timesteps, temperature=0.0,
-                              text_temperature=0.0, cfg_scale=0.0, cfg_img=4.0, uncon_text=job["uncon_text"],
-                              uncon_image=job["uncon_image"], return_state=True)
+    wl = build_workload(args, args.config, None, dev, cfg, tp, world, rank)
+    model, run_once, L = wl["model"], wl["run"], wl["L"]
 
     def barrier():
         if use_dist:
@@ -226,7 +372,7 @@ def main():
         smi.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        vq, _, final_ids = run_once()
+        final_ids = run_once()
     barrier()
     dt = time.perf_counter() - t0
     if smi:
@@ -240,34 +386,16 @@ def main():
         dt = tt.item()
         # outside the timed region: under tensor parallelism every rank must have sampled the same image tokens
         allv = [None] * world
-        dist.all_gather_object(allv, final_ids.tolist())  # all B jobs, before the one random fill of the read-out
+        dist.all_gather_object(allv, final_ids.tolist())  # all jobs, before the one random fill of the read-out
         ranks_agree = all(a == allv[0] for a in allv) if tp > 1 else None
     ar_probe = None
     if use_dist and tp > 1:
-        # outside the timed region: the collective the forward issues 128 times per micro-batch (one micro-batch's residual
-        # stream, bf16), timed alone, so a scaling run also records what the fabric delivered for that message size
-        lane_rows = ((B + 1) // 2) * ((L + 7) // 8 * 8)
-        buf = torch.zeros(lane_rows * cfg["d_model"], dtype=torch.bfloat16, device=dev)
-        for _ in range(3):
-            dist.all_reduce(buf)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(10):
-            dist.all_reduce(buf)
-        torch.cuda.synchronize()
-        ar_ms = (time.perf_counter() - t1) / 10 * 1e3
-        nbytes = buf.numel() * 2
-        ar_probe = {"bytes": nbytes, "ms": ar_ms, "busbw_GBps": 2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9,
-                    "calls_per_forward": 2 * cfg["n_layers"] * 2}
+        ar_probe = model.collective_probe(L) if hasattr(model, "collective_probe") else None
 
     if rank == 0:
-        from mmada_parallel_amd.generators.parallel_generator import image_step_indices
-
-        n_img = len(set(image_step_indices(args.text_steps, args.timesteps)))
-        windowed = os.environ.get("MMADA_NO_WINDOW") != "1"
-        fl_img = job_flops(cfg, L, T, N, args.text_steps, n_img, cfg["embedding_size"], synth.CODEBOOK,
-                           job if windowed else None)
-        images = args.steps * world  # tp: B = world jobs in one group; dp: one job on each of `world` replicas
+        fl_img = wl["flops_per_image"]
+        # tp: ONE group holds all jobs of a step; dp: every rank is a replica running its own step
+        images = args.steps * wl["images_per_step"] * (world if tp == 1 and world > 1 else 1)
         value = images / dt
         kinds = {}
         for i, nm in enumerate(KIND_NAMES):
@@ -276,24 +404,31 @@ def main():
         dom = max(range(5), key=lambda i: ms[i]) if any(cnt) else 3
         ach = fl[dom] / (ms[dom] * 1e-3) / 1e12 if cnt[dom] else 0.0
         out = {
-            "metric": "images/sec (512x512, 64 img + 128 text steps) MMaDA-Parallel-A 8B",
+            "metric": wl["metric"],
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak" if args.config == 1 else "strong", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: MMaDA-Parallel-A 8B, 512x512, timesteps=64, text_steps=128, "
-                                   "cfg_img=4.0, temperature=0, L=2438, 256 forwards/image" + (" [REDUCED DEBUG RUN]" if reduced else ""),
-                       "global_batch": world, "seq_len": L, "parallelism": f"{args.parallelism}{world}",
+            "config": {"workload": wl["workload"] + (" [REDUCED DEBUG RUN]" if reduced else ""),
+                       "baseline_config_index": args.config,
+                       "global_batch": wl["images_per_step"] * (world if tp == 1 and world > 1 else 1), "seq_len": L,
+                       "parallelism": f"{args.parallelism}{world}",
                        "text_steps": args.text_steps, "timesteps": args.timesteps, "n_layers": cfg["n_layers"],
                        "algorithmic_pflop_per_image": fl_img / 1e15,
                        "job_mfma_frac": value * fl_img / 1e12 / (world * MFMA_BF16_PEAK_TFLOPS),
-                       "tp_ranks_agree": ranks_agree, "allreduce_probe": ar_probe,
+                       "hipgraph_step": bool(getattr(model, "graph_replays", 0)),
+                       "tp_ranks_agree": ranks_agree, "tp_collective": getattr(model, "tp_collective", None),
+                       "allreduce_probe": ar_probe,
                        "rocm_smi_during_run": smi.summary() if smi else None,
                        "kernels": kinds},
             "roofline": {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": measured_traffic(KIND_NAMES[dom])},
+                         "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                         "traffic": measured_traffic(KIND_NAMES[dom]) if args.config == 1 else None,
+                         "traffic_source": "profiles/traffic.json: separate rocprofv3 --pmc passes of a shortened "
+                                           "(--text-steps 8 --timesteps 4) run of this command, not this run"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, job)
+            out["cpu_baseline"] = cpu_baseline(cfg, **wl["cpu"])
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()

@@ -133,3 +133,29 @@ class ReplayCpuRng:
 
     def multinomial(self, probs2d, generator):
         return torch.multinomial(probs2d.cpu(), 1, generator=generator).to(probs2d.device)
+
+
+# ---- measured parity numbers (tests/test_gpu_parity_depth.py, test_gpu_fullsize.py) -> gpurun_out/r02_parity.json ----
+PARITY_REPORT = os.path.join(ROOT, "gpurun_out", "r02_parity.json")
+
+
+def save_parity(section, payload):
+    import json
+
+    os.makedirs(os.path.dirname(PARITY_REPORT), exist_ok=True)
+    data = {}
+    if os.path.exists(PARITY_REPORT):
+        try:
+            with open(PARITY_REPORT) as f:
+                data = json.load(f)
+        except Exception:
+            data = {}
+    data[section] = payload
+    with open(PARITY_REPORT, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+
+
+def host_threads():
+    """Oracle matmuls on the physical cores, not on every hyper-thread (oversubscription made round 1's CPU numbers 3x slow)."""
+    n = os.cpu_count() or 8
+    torch.set_num_threads(max(1, n if n <= 64 else n // 2))

@@ -121,9 +121,10 @@ def test_forward_hidden_and_logits_vs_oracle_and_reference(tiny_model):
     scale = ref_hidden.abs().max().item()
     err = (hid - ref_hidden).abs()
     print(f"hidden: max|err|={err.max():.4g} mean|err|={err.mean():.4g} scale={scale:.4g}")
-    # two blocks of bf16 storage: a few bf16 ulps of the stream magnitude
-    assert err.max().item() < 2.0 ** -6 * scale
-    assert err.mean().item() < 2.0 ** -9 * scale
+    # measured (MI355X, rounds 1-2): max 1.05e-2, mean 6.1e-4 of the stream's magnitude after the two blocks; limits are
+    # measured x 1.5 (the numbers of every run are recorded in gpurun_out/r02_parity.json -> profiles/r02_parity.json)
+    assert err.max().item() < 1.6e-2 * scale
+    assert err.mean().item() < 1.0e-3 * scale
 
     pos = torch.from_numpy(z["pos"]).to(DEV)
     img = tiny_model.head_rows(pos.int(), synth.TEXT_VOCAB, synth.TEXT_VOCAB + synth.CODEBOOK).cpu().float()
@@ -131,15 +132,22 @@ def test_forward_hidden_and_logits_vs_oracle_and_reference(tiny_model):
     lscale = img_ref.abs().max().item()
     lerr = (img - img_ref).abs()
     print(f"image logits: max|err|={lerr.max():.4g} mean|err|={lerr.mean():.4g} scale={lscale:.4g}")
-    assert lerr.max().item() < 2.0 ** -5 * lscale
-    assert lerr.mean().item() < 2.0 ** -8 * lscale
+    from helpers import save_parity
+
+    save_parity("tiny_forward_vs_reference_fixture", {
+        "hidden_max_rel": err.max().item() / scale, "hidden_mean_rel": err.mean().item() / scale,
+        "image_logits_max_rel": lerr.max().item() / lscale, "image_logits_mean_rel": lerr.mean().item() / lscale,
+        "oracle_on_this_host_vs_fixture_max_rel": o_err})
+    # measured: max 5.3e-3, mean 7.8e-4 of the logit magnitude
+    assert lerr.max().item() < 1.0e-2 * lscale
+    assert lerr.mean().item() < 1.5e-3 * lscale
 
     job = tiny_job()
     out = tiny_model(ids.to(DEV), infer=True, use_cache=False).logits   # drop-in contract: [B, L, V]
     assert out.shape == (1, ids.shape[1], synth.CFG_TINY["vocab_size"]) and out.dtype == torch.bfloat16
     th = out[0, job["text_start"]:job["text_end"], :4096].cpu().float()
     th_ref = from_bits(z["text_logits_head"]).float()
-    assert (th - th_ref).abs().max().item() < 2.0 ** -5 * th_ref.abs().max().item()
+    assert (th - th_ref).abs().max().item() < 1.5e-2 * th_ref.abs().max().item()
     # argmax agreement with the reference (near-ties may flip: report, require a clear majority)
     agree = (out[0].argmax(-1).cpu().int() == torch.from_numpy(z["argmax"])).float().mean().item()
     print(f"argmax agreement with the reference: {agree:.3f}")
