@@ -260,6 +260,25 @@ size_t mmada_vq_group_norm_scratch_bytes(int B);
 int mmada_profile_begin(mmada_handle* h, int layer);
 int mmada_profile_end(mmada_handle* h, int32_t* count_out /*[5]*/, double* ms_out /*[5]*/, double* flops_out /*[5]*/);
 
+/* ---- hipGraph capture of a launch sequence ---------------------------------------------------------------------
+ * One denoise step of generate_ti2ti is a fixed sequence of launches over fixed buffers: the per-step text k, the image
+ * mask_len and which forwards run are schedule-determined (generators/parallel_generator.py:78-99,157-159,318-327;
+ * SURVEY.md A.5), and the reference's ~3 k `.item()` syncs per image step (:223-230,339-344) do not exist here.  Between
+ * mmada_graph_begin and mmada_graph_end every call documented "capturable" (forward_body, head_rows, the select /
+ * probs / commit kernels, plain device-to-device copies of the caller) issued on `stream` is recorded instead of run;
+ * mmada_graph_launch replays the whole step with one host call.  Requirements: a created (non-default) stream; every
+ * entry point used inside has run once eagerly before (first calls set kernel attributes and carve the workspace);
+ * no allocation and no mmada_profile_begin window inside the capture.  BASELINE.json configs[4]. */
+typedef struct mmada_graph mmada_graph;
+int mmada_graph_begin(void* stream);
+int mmada_graph_end(void* stream, mmada_graph** out);
+/* Leave capture mode after a call inside the sequence failed; nothing is kept. */
+int mmada_graph_abort(void* stream);
+int mmada_graph_launch(mmada_graph* g, void* stream);
+/* Kernel / memset / copy nodes in the captured step (== launches the replay saves the host). */
+int mmada_graph_num_nodes(const mmada_graph* g);
+int mmada_graph_destroy(mmada_graph* g);
+
 /* ---- low-level kernels exposed for parity tests and profiling -------------------------------------------------- */
 
 /* C[M,N] = A[M,K] · W[N,K]^T, bf16 in / fp32 accumulate / bf16 out (F.linear without bias). */

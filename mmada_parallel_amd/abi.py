@@ -78,6 +78,12 @@ SIGNATURES = {
     "mmada_vq_conv2d": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     "mmada_vq_group_norm": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "mmada_vq_group_norm_scratch_bytes": (c_size_t, [c_int]),
+    "mmada_graph_begin": (c_int, [c_void_p]),
+    "mmada_graph_end": (c_int, [c_void_p, C.POINTER(c_void_p)]),
+    "mmada_graph_abort": (c_int, [c_void_p]),
+    "mmada_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "mmada_graph_num_nodes": (c_int, [c_void_p]),
+    "mmada_graph_destroy": (c_int, [c_void_p]),
     "mmada_sdpa": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
 }
 

@@ -66,6 +66,10 @@ struct ProfScope {
     mmada_handle* h; hipStream_t s; bool on; hipEvent_t a{}, b{}; int kind; double flops;
     ProfScope(mmada_handle* h_, int layer, int kind_, double flops_, hipStream_t s_)
         : h(h_), s(s_), on(h_->prof_layer == layer), kind(kind_), flops(flops_) {
+        if (on) {  // a stream under hipGraph capture records nothing: event timing only exists for eager launches
+            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+            if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) on = false;
+        }
         if (!on) return;
         if (h->prof_pool.empty()) {
             (void)hipEventCreate(&a);

@@ -11,6 +11,8 @@ All per-step counts (text k, image mask_len) are schedule-determined (SURVEY A.5
 """
 from __future__ import annotations
 
+import contextlib
+import ctypes as C
 import math
 import os
 from typing import List
@@ -118,10 +120,17 @@ def _ti2ti_steps(
     codebook_size=8192,
     image_step_list=None,
     rng=None,
+    graph=None,
 ):
     """Generator core shared by generate_ti2ti and generate_ti2ti_stepwise: runs the reference loop and yields
     (step, ids, info) after every step; `info` carries the image step's sampled ids (before re-masking) when one ran.
-    `image_step_list` overrides the schedule of image steps (default: reference :157-159)."""
+    `image_step_list` overrides the schedule of image steps (default: reference :157-159).
+
+    `graph` (None = env MMADA_GRAPH=1): replay each kind of step — text-only, image step — as ONE hipGraph
+    (mmada_graph_*): the launches of a step are a fixed sequence over fixed buffers because k, mask_len and the set of
+    forwards are schedule-determined.  The first step of each kind runs eagerly, the second is captured,
+    the rest replay.  Only at temperature == text_temperature == 0 (the image re-mask temperature is a by-value kernel
+    argument that changes every step otherwise) and when the forward issues no host-side collective."""
     if not isinstance(model, LLaDAForMultiModalGeneration):
         raise TypeError("generate_ti2ti (MI355X) needs mmada_parallel_amd.LLaDAForMultiModalGeneration; "
                         "there is no PyTorch fallback path")
@@ -170,72 +179,140 @@ def _ti2ti_steps(
     if uncon_image is not None:
         uncon_image = uncon_image.to(device=device, dtype=torch.long)
 
+    # ---- every buffer a step touches exists before the loop (fixed addresses: a step can be captured and replayed) ----
+    CBs = codebook_size
+    k_cur = torch.zeros(B, dtype=torch.int32, device=device)
+    mlen_cur = torch.zeros(1, dtype=torch.int32, device=device)
+    text_logits = torch.empty((B * T, V), dtype=torch.bfloat16, device=device)
+    cond_vq = torch.empty((B * N, CBs), dtype=torch.bfloat16, device=device) if img_steps else None
+    unc = torch.empty((2 * B, L), dtype=torch.long, device=device) if need_uncond else None
+    unc_vq = torch.empty((2 * B * N, CBs), dtype=torch.bfloat16, device=device) if need_uncond and img_steps else None
+    zeros_vq = None
+    if not need_uncond and (cfg_scale != 0.0 or cfg_img != 0.0) and img_steps:
+        zeros_vq = torch.zeros((B * N, CBs), dtype=torch.bfloat16, device=device)  # reference :275-278
+    noise_buf = torch.zeros((B, N), dtype=torch.bfloat16, device=device)
+    probs = torch.empty((B * N, CBs), dtype=torch.bfloat16, device=device) if temperature != 0 and img_steps else None
+
     masked_left = remaining_text.clone()
     # rows of the residual stream each forward is read at (host-side): the last block only computes those
     windowed = os.environ.get("MMADA_NO_WINDOW") != "1"
     img_win = (pos_list[0], pos_list[-1] + 1)
-    for step in range(text_steps):
-        # ===== forward: conditional logits (reference :177-178), only the rows/columns that are consumed =====
-        is_img = step in img_steps
-        need_text = int(masked_left.sum()) > 0
+
+    def text_part(is_img, need_text):
+        """Conditional forward (reference :177-178) + text step (:181-217): launches only."""
         lo = min(img_win[0] if is_img else L, text_start if need_text or not is_img else L)
         hi = max(img_win[1] if is_img else 0, text_end if need_text or not is_img else 0)
         model.forward_body(ids, consumed=(lo, hi) if windowed else None)
         st = abi.stream_ptr()
-        cond_vq = model.head_rows(img_rows_1, text_vocab_size, text_vocab_size + codebook_size) if is_img else None
-
-        # ===== text step (reference :181-217) =====
+        if is_img:
+            model.head_rows(img_rows_1, text_vocab_size, text_vocab_size + codebook_size, out=cond_vq)
         if need_text:
-            text_logits = model.head_rows(text_rows, 0, V)  # [B*T, V]
+            model.head_rows(text_rows, 0, V, out=text_logits)  # [B*T, V]
             noisy = None
             if text_temperature != 0:
                 noisy = add_gumbel_noise(text_logits.view(B, T, V), temperature=text_temperature,
                                          generator=generator, rng=rng).contiguous()
             abi.check(lib.mmada_text_select(h, text_logits.data_ptr(), abi.ptr(noisy), B, T, V, V, ids.data_ptr(), L,
-                                            text_start, k_dev[step].data_ptr(), scratch.data_ptr(), st),
+                                            text_start, k_cur.data_ptr(), scratch.data_ptr(), st),
                       "mmada_text_select")
-            masked_left = masked_left - num_transfer[:, step]
 
-        info = {"image_step": is_img, "sampled": None}
-        # ===== image step (reference :220-344) =====
-        if is_img:
-            ut = ui = None
-            if need_uncond:
-                # unconditional sequences: prefix overwritten in place, same length (reference :250-259, A.3)
-                unc = ids.repeat(2, 1)
-                if uncon_text is not None:
-                    unc[:B, :uncon_text.shape[1]] = uncon_text
-                if uncon_image is not None:
-                    unc[B:, :uncon_image.shape[1]] = uncon_image
-                # both uncond forwards run whenever either scale > 0 (reference :243); only their image rows are read
-                model.forward_body(unc, consumed=img_win if windowed else None)
-                unc_vq = model.head_rows(img_rows_2, text_vocab_size, text_vocab_size + codebook_size)
-                ut, ui = unc_vq[:B * N], unc_vq[B * N:]
-            elif cfg_scale != 0.0 or cfg_img != 0.0:
-                # reference :275-278: uncond logits are zeros when no uncond input exists
-                ut = ui = torch.zeros_like(cond_vq)
-            probs = None
-            if temperature != 0:
-                probs = torch.empty((B * N, codebook_size), dtype=torch.bfloat16, device=device)
-            abi.check(lib.mmada_image_probs(h, cond_vq.data_ptr(), abi.ptr(ut), abi.ptr(ui), B, N, codebook_size,
-                                            float(cfg_scale), float(cfg_img), abi.ptr(probs), argmax.data_ptr(),
-                                            pmax.data_ptr(), st), "mmada_image_probs")
-            if temperature == 0:
-                sampled, p_sel = argmax, pmax
-            else:
-                s64 = rng.multinomial(probs, generator)
-                p_sel = torch.gather(probs, -1, s64).view(B, N).contiguous()
-                sampled = s64.view(B, N).to(torch.int32).contiguous()
-            ratio = 1.0 * (step + 1) / text_steps
-            img_temp = temperature * (1.0 - ratio)
-            # randn is drawn even at temperature 0 (reference :30-33, A.2) so the RNG stream advances identically
-            noise = rng.randn((B, N), torch.bfloat16, device, generator)
-            abi.check(lib.mmada_image_commit(h, ids.data_ptr(), B, L, pos_map.data_ptr(), N, sampled.data_ptr(),
-                                             p_sel.data_ptr(), noise.data_ptr(), float(img_temp),
-                                             mlen_dev[step:step + 1].data_ptr(), int(text_vocab_size),
-                                             int(codebook_size), st), "mmada_image_commit")
-            info["sampled"] = sampled
-        yield step, ids, info
+    def image_forwards():
+        """Unconditional forwards of an image step (reference :243-274) + dual-CFG soft-max / arg-max (:282-295)."""
+        st = abi.stream_ptr()
+        ut = ui = None
+        if need_uncond:
+            # unconditional sequences: prefix overwritten in place, same length (reference :250-259, A.3)
+            unc[:B].copy_(ids)
+            unc[B:].copy_(ids)
+            if uncon_text is not None:
+                unc[:B, :uncon_text.shape[1]] = uncon_text
+            if uncon_image is not None:
+                unc[B:, :uncon_image.shape[1]] = uncon_image
+            # both uncond forwards run whenever either scale > 0 (reference :243); only their image rows are read
+            model.forward_body(unc, consumed=img_win if windowed else None)
+            model.head_rows(img_rows_2, text_vocab_size, text_vocab_size + codebook_size, out=unc_vq)
+            ut, ui = unc_vq[:B * N], unc_vq[B * N:]
+        elif zeros_vq is not None:
+            ut = ui = zeros_vq  # reference :275-278: uncond logits are zeros when no uncond input exists
+        abi.check(lib.mmada_image_probs(h, cond_vq.data_ptr(), abi.ptr(ut), abi.ptr(ui), B, N, codebook_size,
+                                        float(cfg_scale), float(cfg_img), abi.ptr(probs), argmax.data_ptr(),
+                                        pmax.data_ptr(), st), "mmada_image_probs")
+
+    def image_commit(sampled, p_sel, img_temp):
+        abi.check(lib.mmada_image_commit(h, ids.data_ptr(), B, L, pos_map.data_ptr(), N, sampled.data_ptr(),
+                                         p_sel.data_ptr(), noise_buf.data_ptr(), float(img_temp),
+                                         mlen_cur.data_ptr(), int(text_vocab_size),
+                                         int(codebook_size), abi.stream_ptr()), "mmada_image_commit")
+
+    if graph is None:
+        graph = os.environ.get("MMADA_GRAPH") == "1"
+    graph = bool(graph) and temperature == 0 and text_temperature == 0 and model.graph_capturable()
+    graphs, seen = {}, set()
+    side = torch.cuda.Stream(device=device) if graph else None
+    if graph:  # the legacy default stream cannot be captured: the loop runs on a side stream, ordered after the caller's
+        side.wait_stream(torch.cuda.current_stream(device))
+    try:
+        for step in range(text_steps):
+            is_img = step in img_steps
+            need_text = int(masked_left.sum()) > 0
+            info = {"image_step": is_img, "sampled": None}
+            with torch.cuda.stream(side) if graph else contextlib.nullcontext():
+                k_cur.copy_(k_dev[step])
+                mlen_cur.copy_(mlen_dev[step:step + 1])
+                early_noise = is_img and temperature == 0 and text_temperature == 0
+                if early_noise:
+                    # randn is drawn even at temperature 0 (reference :30-33, A.2) so the RNG stream advances identically;
+                    # nothing else draws in a step at zero temperatures, so it can be drawn ahead of the step's launches
+                    noise_buf.copy_(rng.randn((B, N), torch.bfloat16, device, generator))
+                key = (is_img, need_text)
+                if graph and key in graphs:
+                    abi.check(lib.mmada_graph_launch(graphs[key], abi.stream_ptr()), "mmada_graph_launch")
+                    model.graph_replays += 1
+                else:
+                    capture = graph and key in seen  # first step of a kind: eager (first calls set attributes / carve)
+                    if capture:
+                        abi.check(lib.mmada_graph_begin(abi.stream_ptr()), "mmada_graph_begin")
+                    try:
+                        text_part(is_img, need_text)
+                        if is_img:
+                            image_forwards()
+                            if temperature == 0:
+                                if not early_noise:  # the reference's draw order: text Gumbel noise first (:13-16, :30-33)
+                                    noise_buf.copy_(rng.randn((B, N), torch.bfloat16, device, generator))
+                                image_commit(argmax, pmax, 0.0)
+                    except Exception:
+                        if capture:
+                            lib.mmada_graph_abort(abi.stream_ptr())
+                        raise
+                    if capture:
+                        g = C.c_void_p()
+                        abi.check(lib.mmada_graph_end(abi.stream_ptr(), C.byref(g)), "mmada_graph_end")
+                        graphs[key] = g
+                        model.graph_nodes[key] = lib.mmada_graph_num_nodes(g)
+                        abi.check(lib.mmada_graph_launch(g, abi.stream_ptr()), "mmada_graph_launch")
+                        model.graph_replays += 1
+                    seen.add(key)
+                if need_text:
+                    masked_left = masked_left - num_transfer[:, step]
+                if is_img:
+                    if temperature == 0:
+                        info["sampled"] = argmax
+                    else:
+                        s64 = rng.multinomial(probs, generator)
+                        p_sel = torch.gather(probs, -1, s64).view(B, N).contiguous()
+                        sampled = s64.view(B, N).to(torch.int32).contiguous()
+                        ratio = 1.0 * (step + 1) / text_steps
+                        noise_buf.copy_(rng.randn((B, N), torch.bfloat16, device, generator))  # reference :30-33
+                        image_commit(sampled, p_sel, temperature * (1.0 - ratio))
+                        info["sampled"] = sampled
+            if graph:
+                torch.cuda.current_stream(device).wait_stream(side)  # whoever consumes `ids` sees the finished step
+            yield step, ids, info
+            if graph:
+                side.wait_stream(torch.cuda.current_stream(device))
+    finally:
+        for g in graphs.values():
+            lib.mmada_graph_destroy(g)
     yield text_steps, ids, {"image_step": False, "sampled": None, "pos_list": pos_list}
 
 
@@ -266,17 +343,20 @@ def generate_ti2ti(
     codebook_size=8192,
     return_state=False,
     rng=None,
+    graph=None,
 ):
     """Joint text+image generation; returns (List[int] vq ids, str | List[int] text) like the reference
     (generators/parallel_generator.py:102-368).
 
+    `graph=True` (or MMADA_GRAPH=1) replays every step as one hipGraph (see _ti2ti_steps; BASELINE configs[4]).
     `return_state=True` additionally returns the final `combined_input_ids` *before* the random fill of
     still-masked image tokens (reference :360-362) — the quantity parity tests compare."""
     ids = pos_list = None
     for _step, ids, info in _ti2ti_steps(model, input_ids, text_start, text_end, image_start, seq_len, newline_every,
                                          text_steps, text_gen_length, text_block_length, timesteps, temperature,
                                          text_temperature, cfg_scale, cfg_img, uncon_text, uncon_image, tokenizer,
-                                         remasking, noise_schedule, generator, text_vocab_size, codebook_size, rng=rng):
+                                         remasking, noise_schedule, generator, text_vocab_size, codebook_size, rng=rng,
+                                         graph=graph):
         pos_list = info.get("pos_list", pos_list)
 
     # ===== final read-out (reference :346-368) =====

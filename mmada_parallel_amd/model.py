@@ -98,6 +98,7 @@ class LLaDAForMultiModalGeneration:
         self._ws = None
         self._ws1 = None
         self._ws_bytes = [0, 0]  # bytes registered with the library per activation context
+        self.graph_replays, self.graph_nodes = 0, {}  # hipGraph step replays issued / nodes per captured step kind
         self._handle1 = None
         self._split = None
         self.n_kv_heads = effective_n_kv_heads(config)
@@ -273,15 +274,19 @@ class LLaDAForMultiModalGeneration:
         off = p - ws.data_ptr()
         return ws[off:off + n].view(torch.bfloat16)
 
-    def head_rows(self, rows: torch.Tensor, col_begin: int, col_end: int) -> torch.Tensor:
+    def head_rows(self, rows: torch.Tensor, col_begin: int, col_end: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """logits[r] = lm_head[col_begin:col_end] · ln_f(x[rows[r]]), rows = b*L + l (int32, device).
 
-        `rows` must be batch-major with the same number of rows per batch element (what generate_ti2ti builds)."""
+        `rows` must be batch-major with the same number of rows per batch element (what generate_ti2ti builds).
+        `out` (bf16 [R, col_end - col_begin], contiguous): write there instead of allocating (fixed address: capturable)."""
         rows = rows.to(device=self.device, dtype=torch.int32).contiguous()
         if os.environ.get("MMADA_CHECK_ROWS") == "1" and getattr(self, "_consumed", None) is not None and rows.numel():
             l = rows % self._shape[1]  # debug aid (forces a device sync): rows must lie inside the declared window
             assert int(l.min()) >= self._consumed[0] and int(l.max()) < self._consumed[1], "head_rows outside forward_body(consumed=...)"
-        out = torch.empty((rows.numel(), col_end - col_begin), dtype=torch.bfloat16, device=self.device)
+        if out is None:
+            out = torch.empty((rows.numel(), col_end - col_begin), dtype=torch.bfloat16, device=self.device)
+        elif out.shape != (rows.numel(), col_end - col_begin) or out.dtype != torch.bfloat16 or not out.is_contiguous():
+            raise ValueError("head_rows(out=...): need a contiguous bf16 [rows, col_end - col_begin] tensor")
         st = abi.stream_ptr()
         if getattr(self, "_split", None) is None:
             abi.check(self._lib.mmada_head_rows(self._handle, rows.data_ptr(), rows.numel(), col_begin, col_end,
@@ -343,6 +348,11 @@ class LLaDAForMultiModalGeneration:
         return CausalLMOutputLite(logits=logits)
 
     __call__ = forward
+
+    def graph_capturable(self) -> bool:
+        """True when forward_body / head_rows issue only stream launches (no host-side collective): the sampler may then
+        capture a whole denoise step into one hipGraph (mmada_graph_*)."""
+        return self.tp_size == 1 or getattr(self, "_comm_in_library", False)
 
     def caching(self, enable: bool = True):
         """LLaDAModelLM.caching (model/modeling_llada.py:1417-1421, 1560-1561): switches the dLLM cache bookkeeping on or

@@ -193,9 +193,10 @@ def _stubbed(tiny_model, seed, V):
                 chunks.append(stub_logits(seed, self.n, 1, ids.shape[1], V))
             self._cur = torch.cat(chunks, 0).to(DEV)
 
-        def head_rows(self, rows, c0, c1):
+        def head_rows(self, rows, c0, c1, out=None):
             flat = self._cur.view(-1, V)
-            return flat[rows.long(), c0:c1].contiguous()
+            r = flat[rows.long(), c0:c1].contiguous()
+            return r if out is None else out.copy_(r)
 
     return Stub()
 
@@ -753,3 +754,33 @@ def test_m_t2i_stepwise_decodes_every_step_and_matches_t2i_generate(tiny_model):
     from mmada_parallel_amd.vq import to_uint8_image
     want = to_uint8_image(vq.decode_code(torch.clamp(a, 0, 8191)))[0].cpu().numpy()
     assert (np.asarray(frames[-1][0]) == want).all()
+
+
+# ------------------------------------------------------------------------------------- hipGraph replay of a denoise step
+@pytest.mark.parametrize("case", ["img4", "both", "nocfg"])
+def test_graph_replayed_steps_are_bit_identical_to_eager(tiny_model, case):
+    """generate_ti2ti(graph=True): every step kind is captured once (mmada_graph_*) and replayed; the trajectory must be
+    bit-identical to the eager loop — same kernels, same buffers, same order — including the RNG stream position."""
+    from mmada_parallel_amd import generate_ti2ti
+
+    job, kw = tiny_job(), SAMPLER_CASES[case]
+
+    def run(graph):
+        torch.manual_seed(1234)
+        out = generate_ti2ti(tiny_model, job["input_ids"].to(DEV), job["text_start"], job["text_end"], job["image_start"],
+                             job["seq_len"], job["newline_every"], temperature=0.0, text_temperature=0.0,
+                             uncon_text=job["uncon_text"], uncon_image=job["uncon_image"], return_state=True, graph=graph,
+                             **kw)
+        return out[2], torch.cuda.get_rng_state(0).clone()
+
+    tiny_model.graph_replays, tiny_model.graph_nodes = 0, {}
+    eager, rng_e = run(False)
+    assert tiny_model.graph_replays == 0
+    captured, rng_g = run(True)
+    assert torch.equal(eager, captured)
+    assert torch.equal(rng_e, rng_g), "the device RNG must have advanced exactly as in the eager loop"
+    n_img = len(set(torch.linspace(kw["text_steps"] // 4, kw["text_steps"] - 1, kw["timesteps"]).round().int().tolist()))
+    # the first step of each kind runs eagerly, every other step is a replay
+    assert kw["text_steps"] - 4 <= tiny_model.graph_replays <= kw["text_steps"] - len(tiny_model.graph_nodes)
+    assert all(n > 10 for n in tiny_model.graph_nodes.values()), tiny_model.graph_nodes
+    print(f"{case}: {tiny_model.graph_replays} replays, nodes per step kind {tiny_model.graph_nodes}, image steps {n_img}")
