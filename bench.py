@@ -197,8 +197,13 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
     from mmada_parallel_amd.generators.parallel_generator import image_step_indices
 
     full = synth.full_config(cfg)
-    windowed = os.environ.get("MMADA_NO_WINDOW") != "1"
+    # tensor parallel: the library's exchange keeps every row of the last block (no consumed-row window)
+    windowed = os.environ.get("MMADA_NO_WINDOW") != "1" and tp == 1
     V, CB = cfg["embedding_size"], synth.CODEBOOK
+
+    def connect(model, max_batch, L):
+        if tp > 1:
+            model.init_tp_comm(max_batch=max_batch, max_len=L, transport=os.environ.get("MMADA_TP_TRANSPORT", "auto"))
     if cfgnum in (1, 4):
         from mmada_parallel_amd import LLaDAForMultiModalGeneration, generate_ti2ti
 
@@ -214,6 +219,7 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
         L = ids.shape[1]
         T, N = job["text_end"] - job["text_start"], job["seq_len"]
         state = {}
+        connect(model, 2 * B, L)
 
         def run():
             vq, _, final = generate_ti2ti(model, ids, job["text_start"], job["text_end"], job["image_start"],
@@ -269,6 +275,7 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
         eoi = torch.tensor([126085], device=dev)
         P = 2 + N + 1 + 40
         L = P + 1 + N + 1 + T
+        connect(model, 2, L)
         image_steps = 30 if args.timesteps == 64 else args.timesteps
         state = {}
 

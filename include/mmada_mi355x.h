@@ -92,7 +92,8 @@ int mmada_set_workspace(mmada_handle* h, void* ws, size_t bytes);
  * (model/modeling_xllmx_dimoo.py:41-72, model/modeling_llada.py:1462-1511, 1201-1415) without the dead
  * attention-bias plumbing. */
 
-/* Embedding + all n_layers blocks; leaves the final residual stream resident in the workspace (tp_size == 1). */
+/* Embedding + all n_layers blocks; leaves the final residual stream resident in the workspace.  tp_size > 1: needs a
+ * connected transport (mmada_comm_*), see "tensor-parallel exchange" below. */
 int mmada_forward_body(mmada_handle* h, const int64_t* ids /*device [B,L]*/, int B, int L, void* stream);
 
 /* ln_f + LM head on a row subset (model/modeling_llada.py:1392,1399-1404):
@@ -259,6 +260,48 @@ size_t mmada_vq_group_norm_scratch_bytes(int B);
  * flops (2·M·N·K with M = B·L real rows; attention 4·B·H·L²·128). */
 int mmada_profile_begin(mmada_handle* h, int layer);
 int mmada_profile_end(mmada_handle* h, int32_t* count_out /*[5]*/, double* ms_out /*[5]*/, double* flops_out /*[5]*/);
+
+/* ---- tensor-parallel exchange inside the library (SURVEY.md §8b mmada_allreduce_init, §8e) ----------------------------
+ * New design; the reference runs one replica (inference.py:83-85).  With tp_size > 1 the two row-parallel GEMMs of a block
+ * (attn_out, ff_out; model/modeling_llada.py:741-744, 968-970) leave a partial [B*Lp, d] sum on every rank.  One exchange
+ * = reduce-scatter -> residual add + RMSNorm on the rows this rank owns -> all-gather of the normalised rows
+ * (csrc/tp_comm.hip): the residual stream stays sharded by rows, the all-gathered tensor is the next GEMM's input.
+ * Once a transport is connected, mmada_forward_body runs the whole tensor-parallel forward (exchanges on a second,
+ * high-priority stream, two row chunks in flight so an exchange runs under the neighbouring GEMM also at batch 1);
+ * mmada_head_rows / mmada_read_stream work as at tp_size == 1.  mmada_set_consumed_rows is ignored (every row is kept).
+ *
+ *   mmada_comm_create        allocate the published buffers for up to max_rows (= B*Lp) stream rows; export_out receives
+ *                            mmada_comm_export_bytes() bytes to hand to the other ranks (hipIpc handles), or NULL
+ *   mmada_comm_connect_ipc   peers in OTHER processes: exports = [tp_size][export_bytes] in rank order (own slot ignored)
+ *   mmada_comm_connect_local peers in THIS process (one host driving several devices with peer access, or tests)
+ *   mmada_comm_connect_rccl  RCCL transport (ncclReduceScatter / ncclAllGather issued by the library); unique_id128 from
+ *                            mmada_comm_unique_id on rank 0, distributed by the host; librccl_path NULL = "librccl.so"
+ *                            (pass the path of the library the process already has loaded, e.g. torch/lib/librccl.so)
+ *   mmada_comm_set_mode      switch between connected transports (1 pull, 2 RCCL)
+ *   mmada_comm_status        transport in use, sticky error (a peer never arrived within MMADA_TP_TIMEOUT_S, default 20 s:
+ *                            the device is never hung, the results are void), whether the counters are fine-grained
+ *   mmada_comm_exchange      ONE exchange over the rows of the resident carve with the caller's partials
+ *                            (mmada_comm_part_ptr) — self-tests and bandwidth probes
+ * Every rank must issue the same sequence of forwards / exchanges. */
+int mmada_comm_export_bytes(void);
+int mmada_comm_create(mmada_handle* h, int max_rows, void* export_out);
+int mmada_comm_connect_ipc(mmada_handle* h, const void* exports);
+int mmada_comm_connect_local(mmada_handle* h, mmada_handle* const* ranks);
+int mmada_comm_unique_id(void* out128, const char* librccl_path);
+int mmada_comm_connect_rccl(mmada_handle* h, const void* unique_id128, const char* librccl_path);
+int mmada_comm_set_mode(mmada_handle* h, int mode);
+int mmada_comm_status(mmada_handle* h, int* mode_out, int* err_out, int* finegrained_out, void* stream);
+void* mmada_comm_part_ptr(mmada_handle* h);
+int mmada_comm_exchange(mmada_handle* h, const void* norm_w, void* stream);
+/* Vocabulary-parallel text step after a tensor-parallel forward (generators/parallel_generator.py:185-217 at
+ * text_temperature == 0; LM head model/modeling_llada.py:1399-1404): every rank multiplies the consumed ln_f rows by ITS
+ * vocab/tp_size columns of ff_out.weight, reduces each row to {max, first arg-max, fp64 sum-exp} (16 B), the records are
+ * exchanged and combined (max of maxima; lowest column wins ties = torch.argmax; rescaled sum), and the k[b] most confident
+ * masked positions are committed identically on every rank.  rows: device int32 [B*T] = b*L + text_start + t;
+ * scratch: device, >= B*T*16 bytes. */
+int mmada_text_select_tp(mmada_handle* h, const int32_t* rows, int B, int T, int64_t* ids, int L, int text_start,
+                         const int32_t* k, void* scratch, void* stream);
+int mmada_comm_destroy(mmada_handle* h);
 
 /* ---- hipGraph capture of a launch sequence ---------------------------------------------------------------------
  * One denoise step of generate_ti2ti is a fixed sequence of launches over fixed buffers: the per-step text k, the image

@@ -78,6 +78,18 @@ SIGNATURES = {
     "mmada_vq_conv2d": (c_int, [c_void_p] * 5 + [c_int] * 7 + [c_void_p]),
     "mmada_vq_group_norm": (c_int, [c_void_p] * 5 + [c_int] * 4 + [c_void_p]),
     "mmada_vq_group_norm_scratch_bytes": (c_size_t, [c_int]),
+    "mmada_comm_export_bytes": (c_int, []),
+    "mmada_comm_create": (c_int, [c_void_p, c_int, c_void_p]),
+    "mmada_comm_connect_ipc": (c_int, [c_void_p, c_void_p]),
+    "mmada_comm_connect_local": (c_int, [c_void_p, C.POINTER(c_void_p)]),
+    "mmada_comm_unique_id": (c_int, [c_void_p, C.c_char_p]),
+    "mmada_comm_connect_rccl": (c_int, [c_void_p, c_void_p, C.c_char_p]),
+    "mmada_comm_set_mode": (c_int, [c_void_p, c_int]),
+    "mmada_comm_status": (c_int, [c_void_p, C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_int), c_void_p]),
+    "mmada_comm_part_ptr": (c_void_p, [c_void_p]),
+    "mmada_comm_exchange": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "mmada_text_select_tp": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "mmada_comm_destroy": (c_int, [c_void_p]),
     "mmada_graph_begin": (c_int, [c_void_p]),
     "mmada_graph_end": (c_int, [c_void_p, C.POINTER(c_void_p)]),
     "mmada_graph_abort": (c_int, [c_void_p]),

@@ -10,7 +10,7 @@
 #include <vector>
 
 #include "../../include/mmada_mi355x.h"
-#include "kernels.h"
+#include "handle.h"
 
 static thread_local char g_err[1024] = "";
 
@@ -20,106 +20,6 @@ int mm_fail(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return 1;
-}
-
-struct LayerWeights {
-    bf16_t* wqkv = nullptr;   // [(Hq_l + 2 Hkv_l) * 128, d]   fused, rotary-partner permuted
-    bf16_t* wo = nullptr;     // [d, Hq_l * 128]
-    bf16_t* wgu = nullptr;    // [2 F_l, d]                    16-row interleaved ff_proj / up_proj
-    bf16_t* wdown = nullptr;  // [d, F_l]
-    bf16_t* attn_norm = nullptr;  // [d]
-    bf16_t* ff_norm = nullptr;    // [d]
-    bool bound = false;
-};
-
-struct mmada_handle {
-    mmada_cfg cfg;
-    int hq_l, hkv_l, f_l;  // per-rank heads / mlp columns
-    float* rope_cos = nullptr;
-    float* rope_sin = nullptr;
-    const bf16_t* wte = nullptr;
-    const bf16_t* ln_f = nullptr;
-    const bf16_t* lm_head = nullptr;
-    std::vector<LayerWeights> layers;
-    bool owns_weights = true;  // false for mmada_clone_shared handles
-    // workspace
-    char* ws = nullptr;
-    size_t ws_bytes = 0;
-    // current carve
-    int B = 0, L = 0, Lp = 0, Lkv = 0, M = 0;
-    bf16_t *x = nullptr, *y = nullptr, *xn = nullptr, *att = nullptr, *hbuf = nullptr, *q = nullptr, *k = nullptr,
-           *vT = nullptr, *xg = nullptr;
-    int32_t* rows_all = nullptr;
-    // consumed-row window (mmada_set_consumed_rows): requested [win_beg, win_end) per sequence; while a forward whose
-    // last block ran windowed is resident, the stream is compact: cur_W rows per sequence starting at row cur_beg
-    int win_beg = 0, win_end = 0;
-    int cur_W = 0, cur_beg = 0, Mcur = 0;
-    // live timing (mmada_profile_begin/end)
-    int prof_layer = -1;
-    struct ProfRec { int kind; hipEvent_t a, b; double flops; };
-    std::vector<ProfRec> prof;
-    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_pool;
-};
-
-namespace {
-struct ProfScope {
-    mmada_handle* h; hipStream_t s; bool on; hipEvent_t a{}, b{}; int kind; double flops;
-    ProfScope(mmada_handle* h_, int layer, int kind_, double flops_, hipStream_t s_)
-        : h(h_), s(s_), on(h_->prof_layer == layer), kind(kind_), flops(flops_) {
-        if (on) {  // a stream under hipGraph capture records nothing: event timing only exists for eager launches
-            hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-            if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) on = false;
-        }
-        if (!on) return;
-        if (h->prof_pool.empty()) {
-            (void)hipEventCreate(&a);
-            (void)hipEventCreate(&b);
-        } else {
-            a = h->prof_pool.back().first; b = h->prof_pool.back().second;
-            h->prof_pool.pop_back();
-        }
-        (void)hipEventRecord(a, s);
-    }
-    ~ProfScope() {
-        if (!on) return;
-        (void)hipEventRecord(b, s);
-        h->prof.push_back({kind, a, b, flops});
-    }
-};
-}  // namespace
-
-static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
-static inline int ceil_to(int v, int a) { return (v + a - 1) / a * a; }
-
-struct Carve {
-    size_t x, y, xn, att, h, q, k, vT, xg, rows, total;
-    int Lp, Lkv, M;
-};
-
-static Carve carve_for(const mmada_handle* h, int B, int L) {
-    Carve c;
-    const int d = h->cfg.d_model;
-    c.Lp = ceil_to(L, 8);
-    c.Lkv = ceil_to(L, 64);
-    c.M = B * c.Lp;
-    size_t off = 0;
-    auto take = [&](size_t bytes) {
-        size_t o = off;
-        off = align_up(off + bytes, 256);
-        return o;
-    };
-    c.x = take((size_t)c.M * d * 2);
-    c.y = take((size_t)c.M * d * 2);
-    c.xn = take((size_t)c.M * d * 2);
-    c.att = take((size_t)c.M * h->hq_l * 128 * 2);
-    c.h = take((size_t)c.M * h->f_l * 2);
-    c.q = take((size_t)B * h->hq_l * c.Lkv * 128 * 2);
-    c.k = take((size_t)B * h->hkv_l * c.Lkv * 128 * 2);
-    c.vT = take((size_t)B * h->hkv_l * 128 * c.Lkv * 2);
-    c.xg = take((size_t)B * L * d * 2);
-    c.rows = take((size_t)B * L * 4);
-    c.total = off;
-    return c;
 }
 
 extern "C" {
@@ -176,6 +76,7 @@ int mmada_destroy(mmada_handle* h) {
     if (!h) return 0;
     for (auto& r : h->prof) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (auto& e : h->prof_pool) { (void)hipEventDestroy(e.first); (void)hipEventDestroy(e.second); }
+    tp_comm_free(h);
     if (!h->owns_weights) { delete h; return 0; }
     for (auto& lw : h->layers) {
         (void)hipFree(lw.wqkv); (void)hipFree(lw.wo); (void)hipFree(lw.wgu);
@@ -275,6 +176,7 @@ int mmada_embed(mmada_handle* h, const int64_t* ids, int B, int L, void* stream)
     if (check_bound(h)) return 1;
     if (apply_carve(h, B, L, s)) return 1;
     h->cur_W = 0; h->cur_beg = 0; h->Mcur = h->M;
+    h->xn_is_final = false;
     return launch_embed(ids, h->wte, h->x, B, L, h->Lp, h->cfg.d_model, h->cfg.vocab, s);
 }
 
@@ -387,9 +289,14 @@ size_t mmada_stream_bytes(const mmada_handle* h) { return h ? (size_t)h->Mcur * 
 
 int mmada_forward_body(mmada_handle* h, const int64_t* ids, int B, int L, void* stream) {
     if (!h) return mm_fail("mmada_forward_body: null handle");
-    if (h->cfg.tp_size != 1)
-        return mm_fail("mmada_forward_body: tp_size=%d needs the segment API (mmada_embed/attn_partial/mlp_partial)",
-                       h->cfg.tp_size);
+    if (h->cfg.tp_size != 1) {
+        // tensor parallel: the exchange step lives in the library (tp_comm.hip); the residual stream stays sharded by rows
+        if (!h->tp)
+            return mm_fail("mmada_forward_body: tp_size=%d needs a connected collective (mmada_comm_create + "
+                           "mmada_comm_connect_*) or the host-issued all-reduce of the segment API", h->cfg.tp_size);
+        if (mmada_embed(h, ids, B, L, stream)) return 1;
+        return tp_forward_body(h, (hipStream_t)stream);
+    }
     if (mmada_embed(h, ids, B, L, stream)) return 1;
     for (int i = 0; i < h->cfg.n_layers; ++i) {
         if (mmada_attn_partial(h, i, stream)) return 1;
@@ -409,8 +316,10 @@ int mmada_head_rows(mmada_handle* h, const int32_t* rows, int R, int col_begin, 
     const int d = h->cfg.d_model;
     // a windowed forward left the stream compact: row (b, l) sits at b*cur_W + l - cur_beg; rows outside the window the
     // caller declared with mmada_set_consumed_rows were never computed and must not be requested
-    if (launch_rmsnorm_gather(h->x, h->ln_f, h->xg, rows, R, h->L, h->cur_W ? h->cur_W : h->Lp, d, h->cfg.rms_eps, s,
-                              h->cur_beg, h->B * h->L)) return 1;
+    if (h->xn_is_final) {  // tensor-parallel forward: the last exchange already applied ln_f on the owners' rows
+        if (tp_head_gather(h, rows, R, s)) return 1;
+    } else if (launch_rmsnorm_gather(h->x, h->ln_f, h->xg, rows, R, h->L, h->cur_W ? h->cur_W : h->Lp, d, h->cfg.rms_eps, s,
+                                     h->cur_beg, h->B * h->L)) return 1;
     GemmArgs g{};
     g.A = h->xg; g.W = h->lm_head + (size_t)col_begin * d; g.C = (bf16_t*)logits_out;
     g.M = R; g.N = col_end - col_begin; g.K = d;
@@ -436,6 +345,10 @@ int mmada_forward(mmada_handle* h, const int64_t* ids, int B, int L, void* logit
 int mmada_read_stream(mmada_handle* h, void* out, void* stream) {
     if (!h || h->M == 0 || !out) return mm_fail("mmada_read_stream: no forward resident");
     if (h->cur_W) return mm_fail("mmada_read_stream: the resident stream only holds rows [%d,%d) of each sequence", h->cur_beg, h->cur_beg + h->cur_W);
+    if (h->xn_is_final) {  // rows of the residual stream live on their owners: collect them (parity tap only)
+        if (tp_gather_stream(h, h->y, (hipStream_t)stream)) return 1;
+        return launch_unpad_rows(h->y, (bf16_t*)out, h->B, h->L, h->Lp, h->cfg.d_model, (hipStream_t)stream);
+    }
     return launch_unpad_rows(h->x, (bf16_t*)out, h->B, h->L, h->Lp, h->cfg.d_model, (hipStream_t)stream);
 }
 

@@ -228,7 +228,8 @@ MM_DEVICE void epilogue(const GemmArgs& g, int m0, int n0,
                 for (int r = 0; r < 4; ++r) {
                     const int m = mrow0 + mi * 16 + r;
                     if (m >= g.M) continue;
-                    const int b = m / g.Lp, l = m - b * g.Lp;
+                    const int mg = m + g.m_base;  // row of the whole [B*Lp] stream
+                    const int b = mg / g.Lp, l = mg - b * g.Lp;
                     bf16_t* row = dst + ((size_t)(b * nh + hh) * g.Lkv + l) * 128;
 #pragma unroll
                     for (int q2 = 0; q2 < FN / 2; ++q2) {
@@ -249,7 +250,8 @@ MM_DEVICE void epilogue(const GemmArgs& g, int m0, int n0,
             for (int mi = 0; mi < FM; ++mi) {
                 const int mb = mrow0 + mi * 16;  // multiple of 4; Lp is a multiple of 8 -> 4 rows share a batch
                 if (mb >= g.M) continue;
-                const int b = mb / g.Lp, l0 = mb - b * g.Lp;
+                const int mbg = mb + g.m_base;  // m_base is a multiple of 8: the 4 rows still share a batch element
+                const int b = mbg / g.Lp, l0 = mbg - b * g.Lp;
 #pragma unroll
                 for (int ni = 0; ni < FN; ++ni) {
                     const int d = c0 + ni * 16 + frow;
@@ -280,6 +282,13 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bt_kernel(GemmArgs g) {
         for (int j = 0; j < T::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     mainloop<BM, WM, WN>(g, smem, mt * BM, nt * BN, 0, g.K / BK, acc, wave, lane);
     epilogue<EPI, BM, WM, WN>(g, mt * BM, nt * BN, acc, wave, lane);
+    if (g.publish) {  // hand-off to a peer that polls a counter instead of waiting on a HIP event (csrc/tp_comm.hip)
+        __syncthreads();
+        if (wave == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
 }
 
 template <int EPI, int BM, int WM, int WN>
@@ -368,7 +377,7 @@ int launch_gemm(int epi, const GemmArgs& g_in, hipStream_t s) {
             return launch_t<EPI_SWIGLU>(g, s);
         case EPI_QKV:
             if (g.N != (g.Hq + 2 * g.Hkv) * 128) return mm_fail("gemm/qkv: N mismatch");
-            if (g.Lp % 8) return mm_fail("gemm/qkv: Lp must be a multiple of 8");
+            if (g.Lp % 8 || g.m_base % 8) return mm_fail("gemm/qkv: Lp and m_base must be multiples of 8");
             return launch_t<EPI_QKV>(g, s);
     }
     return mm_fail("gemm: bad epilogue %d", epi);

@@ -30,6 +30,9 @@ struct GemmArgs {
     const float* rope_cos;  // [max_seq, 64]
     const float* rope_sin;  // [max_seq, 64]
     int Lp, Lkv, Hq, Hkv;
+    int publish;       // != 0: C is read by OTHER agents / other XCDs' kernels polling a counter (tensor-parallel partials):
+                       // every workgroup ends with a system-scope release so its stores have left this XCD's L2
+    int m_base;        // EPI_QKV on a row chunk: A/M describe rows [m_base, m_base+M) of the [B*Lp] stream (b, l from m_base+m)
 };
 
 int launch_gemm(int epi, const GemmArgs& g, hipStream_t s);
@@ -60,6 +63,10 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
                      int Lq_rows, int Lkv, int out_row_stride_per_batch, int ld_out, hipStream_t s, int q_begin = 0);
 
 // sampler.hip
+struct TextStat { float lmax; int32_t arg; double sum; };  // one rank's record of a text row (vocabulary-parallel head)
+int launch_text_stats_partial(const bf16_t* logits, int B, int T, int Vl, int ld, int col_off, const int64_t* ids, int L,
+                              int text_start, int mask_id, TextStat* out, hipStream_t s);
+int launch_text_commit(const void* scratch, int B, int T, int64_t* ids, int L, int text_start, const int32_t* k, hipStream_t s);
 int launch_text_select(const bf16_t* logits, const bf16_t* noisy, const bf16_t* unc, float text_cfg, const int32_t* x0_in,
                        int B, int T, int V, int ld, int64_t* ids, int L, int text_start, const int32_t* k, void* scratch,
                        int mask_id, hipStream_t s);

@@ -126,6 +126,77 @@ __global__ __launch_bounds__(TB) void text_row_stats_kernel(const bf16_t* __rest
     }
 }
 
+// Vocabulary-parallel form of part 1 (tensor parallelism, text_temperature == 0): this rank holds the logits of columns
+// [col_off, col_off + Vl) only.  Per masked row it publishes {local max, global index of its first local maximum,
+// sum_j exp(l_j - local max) in fp64}; csrc/tp_comm.hip combines the tp records (max of maxima, the lowest rank holding it
+// = the lowest column index = torch.argmax's first index, rescaled sum) into the same conf / x0 the one-rank kernel writes.
+__global__ __launch_bounds__(TB) void text_row_stats_partial_kernel(const bf16_t* __restrict__ logits, int T, int Vl, int ld,
+                                                                    int col_off, const int64_t* __restrict__ ids, int L,
+                                                                    int text_start, int mask_id,
+                                                                    TextStat* __restrict__ out) {
+    __shared__ float s_val[TB / 64];
+    __shared__ int s_idx[TB / 64];
+    __shared__ double s_sum[TB / 64];
+    const int row = blockIdx.x;
+    const int b = row / T, t = row - b * T;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (ids[(size_t)b * L + text_start + t] != (int64_t)mask_id) {
+        if (tid == 0) out[row] = TextStat{-INFINITY, 0, 0.0};
+        return;
+    }
+    const bf16_t* lrow = logits + (size_t)row * ld;
+    const int nchunk = Vl >> 3;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int c = tid; c < nchunk; c += TB) {
+        const u32x4 lv = ((const u32x4*)lrow)[c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = __uint_as_float(lv[j] << 16), hi = __uint_as_float(lv[j] & 0xffff0000u);
+            if (lo > best) { best = lo; bidx = c * 8 + 2 * j; }
+            if (hi > best) { best = hi; bidx = c * 8 + 2 * j + 1; }
+        }
+    }
+    for (int i = (nchunk << 3) + tid; i < Vl; i += TB) {
+        const float a = bf2f(lrow[i]);
+        if (a > best || (a == best && i < bidx)) { best = a; bidx = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
+    __syncthreads();
+    best = s_val[0]; bidx = s_idx[0];
+#pragma unroll
+    for (int w = 1; w < TB / 64; ++w)
+        if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bidx)) { best = s_val[w]; bidx = s_idx[w]; }
+    if (bidx == 0x7fffffff) bidx = 0;
+    const double dmax = (double)best;
+    double sum = 0.0;
+    for (int c = tid; c < nchunk; c += TB) {
+        const u32x4 lv = ((const u32x4*)lrow)[c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sum += exp((double)__uint_as_float(lv[j] << 16) - dmax);
+            sum += exp((double)__uint_as_float(lv[j] & 0xffff0000u) - dmax);
+        }
+    }
+    for (int i = (nchunk << 3) + tid; i < Vl; i += TB) sum += exp((double)bf2f(lrow[i]) - dmax);
+    sum = wave_sum_d(sum);
+    if (lane == 0) s_sum[wave] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        double tot = 0.0;
+        for (int w = 0; w < TB / 64; ++w) tot += s_sum[w];
+        out[row] = TextStat{best, col_off + bidx, tot};
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // published: read by the other ranks (csrc/tp_comm.hip)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+}
+
 // Text step part 2: per batch row, unmask the k highest-confidence masked positions (:207-217).
 __global__ __launch_bounds__(TB) void text_commit_kernel(const double* __restrict__ conf, const int32_t* __restrict__ x0,
                                                          int T, int64_t* __restrict__ ids, int L, int text_start,
@@ -394,6 +465,25 @@ int launch_image_commit(int64_t* ids, int B, int L, const int32_t* pos_map, int 
     } else
         hipLaunchKernelGGL(image_commit_kernel<false>, dim3(B), dim3(1024), (size_t)N * 8, s, ids, L, pos_map, N, sampled_in,
                            p_in, noise, remask_temp, mask_len_sched, mask_id, text_vocab, codebook, 0);
+    MM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_text_stats_partial(const bf16_t* logits, int B, int T, int Vl, int ld, int col_off, const int64_t* ids, int L,
+                              int text_start, int mask_id, TextStat* out, hipStream_t s) {
+    if (B * T <= 0) return 0;
+    if (ld % 8) return mm_fail("text_stats_partial: ld must be a multiple of 8");
+    hipLaunchKernelGGL(text_row_stats_partial_kernel, dim3(B * T), dim3(TB), 0, s, logits, T, Vl, ld, col_off, ids, L,
+                       text_start, mask_id, out);
+    MM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_text_commit(const void* scratch, int B, int T, int64_t* ids, int L, int text_start, const int32_t* k, hipStream_t s) {
+    if (T > 8192) return mm_fail("text_commit: T=%d too large", T);
+    const double* conf = (const double*)scratch;
+    const int32_t* x0 = (const int32_t*)((const char*)scratch + (size_t)B * T * 8);
+    hipLaunchKernelGGL(text_commit_kernel, dim3(B), dim3(TB), (size_t)T * 8, s, conf, x0, T, ids, L, text_start, k);
     MM_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -1,0 +1,745 @@
+// tp_comm.hip — the tensor-parallel exchange step of the denoiser forward, inside the library (SURVEY.md §8b
+// mmada_allreduce_init, §8e).  The reference has no tensor parallelism (inference.py:83-85 loads one replica); this is
+// the one place the 8B block needs a collective: after each of the two row-parallel GEMMs (attn_out, ff_out;
+// model/modeling_llada.py:741-744, 968-970) every rank holds a partial [M, d] sum.
+//
+// Instead of an all-reduce of the replicated residual stream followed by a replicated RMSNorm, one exchange is
+//     reduce-scatter  ->  residual add + RMSNorm on the 1/tp rows this rank OWNS  ->  all-gather of the normalised rows
+// so the residual stream itself is never communicated (each rank keeps only its own rows of it), the RMSNorm work is
+// divided by tp, and the all-gathered tensor is exactly the A operand of the next column-parallel GEMM (or, after the
+// last block, ln_f(x) for the LM head).  Bytes on the fabric are those of one all-reduce.
+//
+// Two transports behind the same step:
+//   pull (mode 1)  every rank maps its peers' published buffers (hipIpc handles between processes, plain pointers for
+//                  peers in one process) and only ever READS remote memory: the reduce kernel pulls the tp partial
+//                  slices of its own rows with system-scope loads and sums them in rank order (deterministic); the
+//                  gather kernel pulls the other owners' normalised rows.  Everything a GEMM reads was therefore written
+//                  by a kernel of its own device.  Hand-offs are monotonic sequence counters in fine-grained memory,
+//                  published by a 1-thread kernel after the producing kernel has retired and awaited by a 1-wave kernel
+//                  (bounded spin: a lost peer raises an error flag, it never hangs the device).  The counters live in
+//                  device memory, so the whole exchange is hipGraph-replayable.  xGMI is a full mesh of point-to-point
+//                  links: the tp-1 pulls of a rank run over tp-1 different links at once (SURVEY.md §5.8 two-shot).
+//   RCCL (mode 2)  ncclReduceScatter / ncclAllGather issued from here (librccl is dlopen'ed: no link-time dependency, the
+//                  host may hand in the library torch already loaded), same owner-side kernel in between.
+// Overlap: the M rows are cut into two chunks; the exchange of chunk i runs on a second (high-priority) stream under the
+// row-parallel GEMM of chunk i+1 / the next column-parallel GEMM of chunk i-1 — also at batch 1, the only join point is
+// the attention (needs every key).
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstdlib>
+#include <cstring>
+
+#include "handle.h"
+
+namespace {
+
+constexpr int TP_MAX = 8;
+constexpr int MAXCH = 8;  // 16-B chunks per lane: d <= 4096
+
+constexpr int STAT_ROWS = 16384;  // text rows (B*T) a vocabulary-parallel select can take
+
+struct TpPeers {
+    const bf16_t* part[TP_MAX];
+    const bf16_t* hn[TP_MAX];
+    const uint32_t* ctr[TP_MAX];
+    const TextStat* stats[TP_MAX];
+};
+
+struct RcclApi {
+    void* dl = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+}  // namespace
+
+struct TpComm {
+    int mode = 0;  // 0: buffers allocated, not connected; 1: pull over mapped peer buffers; 2: RCCL
+    int rank = 0, size = 1, max_rows = 0, d = 0;
+    bf16_t* part = nullptr;    // [max_rows + 8*size, d]  published: this rank's partial of the row-parallel GEMM
+    bf16_t* hn_pub = nullptr;  // [max_rows + 8*size, d]  published: normalised rows this rank owns (at their global row)
+    uint32_t* ctr = nullptr;   // [16] published sequence counter (fine-grained memory when the runtime grants it)
+    TextStat* stats_pub = nullptr;  // [STAT_ROWS] published: this rank's per-row record of the vocabulary-parallel text head
+    TextStat* stats_all = nullptr;  // [size][STAT_ROWS] RCCL transport: all-gathered records
+    bf16_t* head_buf = nullptr;     // [head_rows, ceil(V/size)] this rank's logit slice (allocated at first use)
+    size_t head_bytes = 0;
+    uint32_t* seq = nullptr;   // [1]  private: number of hand-offs this rank has published
+    int* err = nullptr;        // [1]  private: != 0 after a wait timed out (1 + the peer that never arrived)
+    bool ctr_fine = false;
+    TpPeers peers{};
+    void* opened[4][TP_MAX] = {};
+    hipStream_t sc = nullptr;  // exchange stream
+    hipEvent_t ev_g[2] = {}, ev_c[2] = {};
+    int chunks = 2;
+    // RCCL
+    RcclApi nccl;
+    ncclComm_t comm = nullptr;
+    bf16_t* rs_tmp = nullptr;  // [ceil(max_rows/size)+8, d]
+};
+
+namespace {
+
+// ---- hand-off ------------------------------------------------------------------------------------------------------
+__global__ void tp_signal_kernel(uint32_t* seq, uint32_t* ctr) {
+    const uint32_t v = *seq + 1u;
+    *seq = v;
+    // the producing kernel retired before this one started (stream order; its end-of-kernel release wrote the XCD L2s
+    // back); this fence + drain orders the counter behind everything this agent has written
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_store(ctr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ void tp_wait_kernel(const uint32_t* seq, TpPeers p, int size, int rank, int* err, long long timeout_ticks) {
+    const int j = threadIdx.x;
+    if (j < size && j != rank && *err == 0) {
+        const uint32_t v = *seq;
+        const long long t0 = wall_clock64();
+        while ((int)(__hip_atomic_load(p.ctr[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - v) < 0) {
+            __builtin_amdgcn_s_sleep(20);
+            if (wall_clock64() - t0 > timeout_ticks) {  // never hang the device: flag it, results are void
+                *err = 1 + j;
+                break;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+}
+
+// 16 bytes of a peer's buffer, system scope (never served from this agent's caches)
+MM_DEVICE u32x4 load_sys16(const bf16_t* p) {
+    const uint64_t* q = (const uint64_t*)p;
+    const uint64_t a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint64_t b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return u32x4{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+}
+
+struct ReduceArgs {
+    TpPeers p;
+    int size, rank;
+    int nsrc;              // pull: = size (source j = rank j's partial, the own one read locally); RCCL: 1 (pre-summed rows)
+    const bf16_t* presum;  // RCCL: [r1 - r0, d] rows already summed over ranks (row 0 = global row r0)
+    const bf16_t* part;    // this rank's own partial [*, d]
+    bf16_t* x;             // residual stream [*, d]: rows [r0, r1) are this rank's, updated in place
+    const bf16_t* w;       // RMSNorm weight [d]
+    bf16_t* hn_pub;        // published normalised rows (global row index)
+    bf16_t* xn;            // this rank's full normalised buffer: own rows are written here directly
+    int r0, r1, d;
+    float eps;
+};
+
+// One wave per owned row:  s = sum_j partial_j[m]  (fp32, rank order) ; out = bf16(s) ; x[m] = bf16(x[m] + out)
+// (the reference: x + attn_out(att) / x + ff_out(h), model/modeling_llada.py:953, 968-970 — every nn.Linear output is
+// rounded to bf16 before the residual add) ; hn = RMSLayerNorm(x[m]) (:315-329, cast-then-scale, same summation order as
+// rmsnorm_row in elementwise.hip, so a row normalises to the same bits on any rank count).
+__global__ __launch_bounds__(256) void tp_reduce_norm_kernel(ReduceArgs a) {
+    const int m = a.r0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.r1) return;
+    // consumer side of the hand-off (guide G16): the wait kernel saw every peer's counter, but THIS wave's caches may still
+    // hold lines of the peers' buffers from the previous exchange
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    const int lane = threadIdx.x & 63;
+    const int nchunk = a.d >> 3;
+    u32x4 xv[MAXCH];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c >= nchunk) break;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        if (a.presum) {
+            const u32x4 v = ((const u32x4*)(a.presum + (size_t)(m - a.r0) * a.d))[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] = __uint_as_float(v[e] << 16);
+                acc[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u);
+            }
+        } else {
+            for (int j = 0; j < a.size; ++j) {
+                const u32x4 v = (j == a.rank) ? ((const u32x4*)(a.part + (size_t)m * a.d))[c]
+                                              : load_sys16(a.p.part[j] + (size_t)m * a.d + c * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] += __uint_as_float(v[e] << 16);
+                    acc[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u);
+                }
+            }
+        }
+        const u32x4 r = ((const u32x4*)(a.x + (size_t)m * a.d))[c];
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = bfround(__uint_as_float(r[e] << 16) + bfround(acc[2 * e]));
+            const float hi = bfround(__uint_as_float(r[e] & 0xffff0000u) + bfround(acc[2 * e + 1]));
+            ss += lo * lo;
+            ss += hi * hi;
+            o[e] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+        }
+        xv[i] = o;
+        ((u32x4*)(a.x + (size_t)m * a.d))[c] = o;
+    }
+    ss = wave_sum(ss);
+    const float var = ss / (float)a.d;
+    const float rs = 1.0f / sqrtf(var + a.eps);
+#pragma unroll
+    for (int i = 0; i < MAXCH; ++i) {
+        const int c = lane + 64 * i;
+        if (c >= nchunk) break;
+        const u32x4 wv = ((const u32x4*)a.w)[c];
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float lo = __uint_as_float(xv[i][e] << 16), hi = __uint_as_float(xv[i][e] & 0xffff0000u);
+            const float wl = __uint_as_float(wv[e] << 16), wh = __uint_as_float(wv[e] & 0xffff0000u);
+            o[e] = pack_bf2(wl * bfround(lo * rs), wh * bfround(hi * rs));
+        }
+        ((u32x4*)(a.hn_pub + (size_t)m * a.d))[c] = o;
+        ((u32x4*)(a.xn + (size_t)m * a.d))[c] = o;
+    }
+    // producer side: the published row must have left this XCD's L2 before the counter that follows this kernel moves
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// rows [m0, m1) owned by other ranks: pull them from their owner's published buffer into dst (one wave per row)
+__global__ __launch_bounds__(256) void tp_gather_kernel(TpPeers p, int rank, int m0, int m1, int slice, int d,
+                                                        bf16_t* dst, int use_part) {
+    const int m = m0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= m1) return;
+    const int owner = (m - m0) / slice;
+    if (owner == rank) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // see tp_reduce_norm_kernel
+    const bf16_t* src = (use_part ? p.part[owner] : p.hn[owner]) + (size_t)m * d;
+    const int nchunk = d >> 3;
+    for (int c = threadIdx.x & 63; c < nchunk; c += 64) ((u32x4*)(dst + (size_t)m * d))[c] = load_sys16(src + c * 8);
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* src, bf16_t* dst, int r0, int r1, int d) {
+    const int m = r0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= r1) return;
+    for (int c = threadIdx.x & 63; c < (d >> 3); c += 64) ((u32x4*)(dst + (size_t)m * d))[c] = ((const u32x4*)(src + (size_t)m * d))[c];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");  // dst may be a published buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// out[r] = src[b*Lp + l] for rows[r] = b*L + l (LM-head rows of an already normalised stream)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* src, const int32_t* rows, int R, int L, int Lp, int d,
+                                                          int nflat, bf16_t* out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const int flat = min(max(rows[r], 0), nflat - 1);
+    const int b = flat / L, l = flat - b * L;
+    const u32x4* s = (const u32x4*)(src + ((size_t)b * Lp + l) * d);
+    for (int c = threadIdx.x & 63; c < (d >> 3); c += 64) ((u32x4*)(out + (size_t)r * d))[c] = s[c];
+}
+
+// Vocabulary-parallel text head: combine the tp per-rank records of every row into the conf (fp64 soft-max probability of
+// the arg-max, generators/parallel_generator.py:185-205) and x0 the one-rank kernel writes.  One thread per row.
+__global__ void tp_text_combine_kernel(TpPeers p, int size, int rank, const TextStat* own, const TextStat* gathered,
+                                       int stat_stride, int R, double* conf_out, int32_t* x0_out) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= R) return;
+    if (!gathered) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    TextStat st[TP_MAX];
+    for (int j = 0; j < size; ++j) {
+        if (gathered) st[j] = gathered[(size_t)j * stat_stride + row];
+        else if (j == rank) st[j] = own[row];
+        else {
+            const uint64_t* q = (const uint64_t*)(p.stats[j] + row);
+            const uint64_t a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const uint64_t b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            st[j].lmax = __uint_as_float((uint32_t)a);
+            st[j].arg = (int32_t)(a >> 32);
+            st[j].sum = __longlong_as_double((long long)b);
+        }
+    }
+    float mx = -INFINITY;
+    int arg = 0;
+    for (int j = 0; j < size; ++j)
+        if (st[j].lmax > mx) { mx = st[j].lmax; arg = st[j].arg; }  // strict >: the lowest rank (lowest column) wins a tie
+    if (!(mx > -INFINITY)) {  // not a masked position (or an all -inf row)
+        conf_out[row] = -INFINITY;
+        x0_out[row] = 0;
+        return;
+    }
+    double tot = 0.0;
+    for (int j = 0; j < size; ++j)
+        if (st[j].lmax > -INFINITY) tot += st[j].sum * exp((double)st[j].lmax - (double)mx);
+    conf_out[row] = 1.0 / tot;  // exp(l[x0] - max) / sum with x0 the arg-max
+    x0_out[row] = arg;
+}
+
+// One wave on (at least) every XCD writes that XCD's L2 back: for partials that were NOT produced by a publishing kernel
+// of this library (mmada_comm_exchange: the caller filled the buffer with its own kernels).  Workgroup b runs on XCD b % 8.
+__global__ void tp_flush_kernel() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+long long timeout_ticks() {
+    static const long long t = [] {
+        const char* e = getenv("MMADA_TP_TIMEOUT_S");
+        const double sec = e ? atof(e) : 20.0;
+        return (long long)(sec * 100e6);  // wall_clock64 runs at 100 MHz on gfx9
+    }();
+    return t;
+}
+
+int signal_wait(TpComm* c, hipStream_t s) {
+    hipLaunchKernelGGL(tp_signal_kernel, dim3(1), dim3(1), 0, s, c->seq, c->ctr);
+    hipLaunchKernelGGL(tp_wait_kernel, dim3(1), dim3(64), 0, s, c->seq, c->peers, c->size, c->rank, c->err, timeout_ticks());
+    MM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+struct Slice { int m0, m1, slice, r0, r1; };
+
+// chunk k of `nch` over M rows; every chunk but the last is a multiple of 8*tp rows, so only the last one is padded
+Slice chunk_slice(int M, int tp, int rank, int nch, int k) {
+    Slice s;
+    const int unit = 8 * tp;
+    const int first = nch == 2 ? (M / 2 + unit - 1) / unit * unit : M;
+    s.m0 = k == 0 ? 0 : min(first, M);
+    s.m1 = (k == nch - 1) ? M : min(first, M);
+    const int rows = s.m1 - s.m0;
+    s.slice = max(8, ((rows + tp - 1) / tp + 7) / 8 * 8);
+    s.r0 = min(s.m1, s.m0 + rank * s.slice);
+    s.r1 = min(s.m1, s.r0 + s.slice);
+    return s;
+}
+
+int nccl_fail(TpComm* c, const char* what, ncclResult_t r) {
+    return mm_fail("%s: %s", what, c->nccl.GetErrorString ? c->nccl.GetErrorString(r) : "RCCL error");
+}
+
+// One exchange over rows [m0, m1): partial sums in c->part  ->  x (own rows), xn (all rows) ; on stream s
+int exchange(mmada_handle* h, const Slice& sl, const bf16_t* norm_w, hipStream_t s) {
+    TpComm* c = h->tp;
+    const int d = h->cfg.d_model;
+    ReduceArgs a{};
+    a.p = c->peers; a.size = c->size; a.rank = c->rank;
+    a.part = c->part; a.x = h->x; a.w = norm_w; a.hn_pub = c->hn_pub; a.xn = h->xn;
+    a.r0 = sl.r0; a.r1 = sl.r1; a.d = d; a.eps = h->cfg.rms_eps;
+    const int own = sl.r1 - sl.r0;
+    if (c->mode == 1) {
+        if (signal_wait(c, s)) return 1;  // every rank's partial of this chunk is complete
+        a.nsrc = c->size;
+        if (own > 0) hipLaunchKernelGGL(tp_reduce_norm_kernel, dim3((own + 3) / 4), dim3(256), 0, s, a);
+        if (signal_wait(c, s)) return 1;  // every owner's normalised rows are published
+        hipLaunchKernelGGL(tp_gather_kernel, dim3((sl.m1 - sl.m0 + 3) / 4), dim3(256), 0, s, c->peers, c->rank, sl.m0, sl.m1,
+                           sl.slice, d, h->xn, 0);
+        MM_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
+    if (c->mode == 2) {
+        const size_t cnt = (size_t)sl.slice * d;
+        ncclResult_t r = c->nccl.ReduceScatter(c->part + (size_t)sl.m0 * d, c->rs_tmp, cnt, ncclBfloat16, ncclSum, c->comm, s);
+        if (r != ncclSuccess) return nccl_fail(c, "ncclReduceScatter", r);
+        a.nsrc = 1; a.presum = c->rs_tmp;
+        if (own > 0) hipLaunchKernelGGL(tp_reduce_norm_kernel, dim3((own + 3) / 4), dim3(256), 0, s, a);
+        MM_CHECK_HIP(hipGetLastError());
+        // every rank contributes its `slice` rows (rows past M are pad rows of the buffers: never read by a GEMM)
+        r = c->nccl.AllGather(c->hn_pub + (size_t)(sl.m0 + c->rank * sl.slice) * d, h->xn + (size_t)sl.m0 * d, cnt,
+                              ncclBfloat16, c->comm, s);
+        if (r != ncclSuccess) return nccl_fail(c, "ncclAllGather", r);
+        return 0;
+    }
+    return mm_fail("tensor-parallel forward: no transport connected (mmada_comm_connect_ipc / _local / _rccl)");
+}
+
+int load_rccl(RcclApi* api, const char* path) {
+    if (api->dl) return 0;
+    const char* cand[3] = {path && path[0] ? path : nullptr, "librccl.so", "librccl.so.1"};
+    for (const char* p : cand) {
+        if (!p) continue;
+        api->dl = dlopen(p, RTLD_NOW | RTLD_GLOBAL);
+        if (api->dl) break;
+    }
+    if (!api->dl) return mm_fail("RCCL: cannot dlopen librccl (%s)", dlerror());
+#define LOAD(field, sym)                                                            \
+    api->field = (decltype(api->field))dlsym(api->dl, sym);                        \
+    if (!api->field) return mm_fail("RCCL: symbol %s missing", sym)
+    LOAD(GetUniqueId, "ncclGetUniqueId");
+    LOAD(CommInitRank, "ncclCommInitRank");
+    LOAD(CommDestroy, "ncclCommDestroy");
+    LOAD(ReduceScatter, "ncclReduceScatter");
+    LOAD(AllGather, "ncclAllGather");
+    LOAD(GetErrorString, "ncclGetErrorString");
+#undef LOAD
+    return 0;
+}
+
+struct CommExport {  // what a rank hands its peers (mmada_comm_create -> mmada_comm_connect_ipc): 4 x 64 B
+    hipIpcMemHandle_t part, hn, ctr, stats;
+};
+
+}  // namespace
+
+// ---- forward ---------------------------------------------------------------------------------------------------------
+// All blocks of a tensor-parallel forward.  h->x holds the embeddings (replicated), every rank keeps its own rows of the
+// residual stream from here on.  Compute on `s`, exchanges on the library's second stream.
+int tp_forward_body(mmada_handle* h, hipStream_t s) {
+    TpComm* c = h->tp;
+    if (!c || c->mode == 0) return mm_fail("tensor-parallel forward: no transport connected (mmada_comm_create + connect)");
+    if (h->M > c->max_rows) return mm_fail("tensor-parallel forward: %d rows exceed the comm buffers (%d)", h->M, c->max_rows);
+    const int d = h->cfg.d_model, tp = c->size, M = h->M, nl = h->cfg.n_layers;
+    if ((d >> 3) > 64 * MAXCH) return mm_fail("tensor-parallel forward: d_model > %d is not supported", 64 * MAXCH * 8);
+    const int nch = (c->chunks >= 2 && M >= 4 * 8 * tp) ? 2 : 1;
+    Slice sl[2];
+    for (int k = 0; k < nch; ++k) sl[k] = chunk_slice(M, tp, c->rank, nch, k);
+    const double rows_real = (double)h->B * h->L / M;  // fraction of stream rows that are not padding (FLOP accounting)
+    // first RMSNorm of the forward: the embeddings are replicated, no exchange needed
+    if (launch_rmsnorm(h->x, h->layers[0].attn_norm, h->xn, M, d, h->cfg.rms_eps, s)) return 1;
+    bool pending[2] = {false, false};  // chunk k's xn rows are being produced on the exchange stream
+    auto after_gemm_exchange = [&](int k, const bf16_t* w) -> int {
+        MM_CHECK_HIP(hipEventRecord(c->ev_g[k], s));
+        MM_CHECK_HIP(hipStreamWaitEvent(c->sc, c->ev_g[k], 0));
+        if (exchange(h, sl[k], w, c->sc)) return 1;
+        MM_CHECK_HIP(hipEventRecord(c->ev_c[k], c->sc));
+        pending[k] = true;
+        return 0;
+    };
+    auto need_xn = [&](int k) -> int {
+        if (pending[k]) {
+            MM_CHECK_HIP(hipStreamWaitEvent(s, c->ev_c[k], 0));
+            pending[k] = false;
+        }
+        return 0;
+    };
+    for (int layer = 0; layer < nl; ++layer) {
+        const LayerWeights& lw = h->layers[layer];
+        // ---- q/k/v (column-parallel: this rank's heads), RoPE in the epilogue ----
+        for (int k = 0; k < nch; ++k) {
+            if (need_xn(k)) return 1;
+            GemmArgs g{};
+            g.A = h->xn + (size_t)sl[k].m0 * d; g.W = lw.wqkv; g.C = nullptr;
+            g.M = sl[k].m1 - sl[k].m0; g.N = (h->hq_l + 2 * h->hkv_l) * 128; g.K = d;
+            g.lda = d; g.ldw = d; g.ldc = 0; g.m_base = sl[k].m0;
+            g.q = h->q; g.k = h->k; g.vT = h->vT; g.rope_cos = h->rope_cos; g.rope_sin = h->rope_sin;
+            g.Lp = h->Lp; g.Lkv = h->Lkv; g.Hq = h->hq_l; g.Hkv = h->hkv_l;
+            ProfScope p(h, layer, 0, 2.0 * g.M * rows_real * g.N * g.K, s);
+            if (launch_gemm(EPI_QKV, g, s)) return 1;
+        }
+        {   // ---- attention over this rank's heads: the one join point (every key of a sequence) ----
+            ProfScope p(h, layer, 1, 4.0 * h->hq_l * (double)h->B * h->L * h->L * 128.0, s);
+            if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->Lp, h->Lkv, h->Lp,
+                                 h->hq_l * 128, s)) return 1;
+        }
+        // ---- attn_out (row-parallel) chunk by chunk; chunk k's exchange runs under chunk k+1's GEMM ----
+        for (int k = 0; k < nch; ++k) {
+            GemmArgs o{};
+            o.A = h->att + (size_t)sl[k].m0 * h->hq_l * 128; o.W = lw.wo; o.C = c->part + (size_t)sl[k].m0 * d;
+            o.M = sl[k].m1 - sl[k].m0; o.N = d; o.K = h->hq_l * 128;
+            o.lda = o.K; o.ldw = o.K; o.ldc = d; o.publish = c->mode == 1;
+            {
+                ProfScope p(h, layer, 2, 2.0 * o.M * rows_real * o.N * o.K, s);
+                if (launch_gemm(EPI_STORE, o, s)) return 1;
+            }
+            if (after_gemm_exchange(k, lw.ff_norm)) return 1;
+        }
+        // ---- gate/up (column-parallel) + SiLU*mul, then down (row-parallel) ----
+        for (int k = 0; k < nch; ++k) {
+            if (need_xn(k)) return 1;
+            GemmArgs g{};
+            g.A = h->xn + (size_t)sl[k].m0 * d; g.W = lw.wgu; g.C = h->hbuf + (size_t)sl[k].m0 * h->f_l;
+            g.M = sl[k].m1 - sl[k].m0; g.N = 2 * h->f_l; g.K = d;
+            g.lda = d; g.ldw = d; g.ldc = h->f_l;
+            ProfScope p(h, layer, 3, 2.0 * g.M * rows_real * g.N * g.K, s);
+            if (launch_gemm(EPI_SWIGLU, g, s)) return 1;
+        }
+        const bf16_t* next_w = layer + 1 < nl ? h->layers[layer + 1].attn_norm : h->ln_f;
+        for (int k = 0; k < nch; ++k) {
+            GemmArgs o{};
+            o.A = h->hbuf + (size_t)sl[k].m0 * h->f_l; o.W = lw.wdown; o.C = c->part + (size_t)sl[k].m0 * d;
+            o.M = sl[k].m1 - sl[k].m0; o.N = d; o.K = h->f_l;
+            o.lda = h->f_l; o.ldw = h->f_l; o.ldc = d; o.publish = c->mode == 1;
+            {
+                ProfScope p(h, layer, 4, 2.0 * o.M * rows_real * o.N * o.K, s);
+                if (launch_gemm(EPI_STORE, o, s)) return 1;
+            }
+            if (after_gemm_exchange(k, next_w)) return 1;
+        }
+    }
+    for (int k = 0; k < nch; ++k)
+        if (need_xn(k)) return 1;
+    h->xn_is_final = true;  // xn = ln_f(x) on every row
+    return 0;
+}
+
+// Residual stream of every owner -> full [M, d] (parity taps; the forward itself never moves the residual stream)
+int tp_gather_stream(mmada_handle* h, bf16_t* full_out, hipStream_t s) {
+    TpComm* c = h->tp;
+    if (!c || c->mode == 0) return mm_fail("tp_gather_stream: no transport connected");
+    const int d = h->cfg.d_model, M = h->M;
+    const int nch = (c->chunks >= 2 && M >= 4 * 8 * c->size) ? 2 : 1;
+    for (int k = 0; k < nch; ++k) {
+        const Slice sl = chunk_slice(M, c->size, c->rank, nch, k);
+        const int own = sl.r1 - sl.r0;
+        if (own > 0) {
+            hipLaunchKernelGGL(copy_rows_kernel, dim3((own + 3) / 4), dim3(256), 0, s, h->x, c->hn_pub, sl.r0, sl.r1, d);
+            hipLaunchKernelGGL(copy_rows_kernel, dim3((own + 3) / 4), dim3(256), 0, s, h->x, full_out, sl.r0, sl.r1, d);
+        }
+        if (c->mode == 1) {
+            if (signal_wait(c, s)) return 1;
+            hipLaunchKernelGGL(tp_gather_kernel, dim3((sl.m1 - sl.m0 + 3) / 4), dim3(256), 0, s, c->peers, c->rank, sl.m0,
+                               sl.m1, sl.slice, d, full_out, 0);
+            if (signal_wait(c, s)) return 1;  // hn_pub may be overwritten only after every peer has pulled
+        } else {
+            ncclResult_t r = c->nccl.AllGather(c->hn_pub + (size_t)(sl.m0 + c->rank * sl.slice) * d,
+                                               full_out + (size_t)sl.m0 * d, (size_t)sl.slice * d, ncclBfloat16, c->comm, s);
+            if (r != ncclSuccess) return nccl_fail(c, "ncclAllGather", r);
+        }
+        MM_CHECK_HIP(hipGetLastError());
+    }
+    return 0;
+}
+
+void tp_comm_free(mmada_handle* h) {
+    TpComm* c = h->tp;
+    if (!c) return;
+    for (int j = 0; j < TP_MAX; ++j)
+        for (int b = 0; b < 4; ++b)
+            if (c->opened[b][j]) (void)hipIpcCloseMemHandle(c->opened[b][j]);
+    if (c->comm && c->nccl.CommDestroy) (void)c->nccl.CommDestroy(c->comm);
+    for (int k = 0; k < 2; ++k) {
+        if (c->ev_g[k]) (void)hipEventDestroy(c->ev_g[k]);
+        if (c->ev_c[k]) (void)hipEventDestroy(c->ev_c[k]);
+    }
+    if (c->sc) (void)hipStreamDestroy(c->sc);
+    (void)hipFree(c->part); (void)hipFree(c->hn_pub); (void)hipFree(c->ctr); (void)hipFree(c->seq); (void)hipFree(c->err);
+    (void)hipFree(c->rs_tmp); (void)hipFree(c->stats_pub); (void)hipFree(c->stats_all); (void)hipFree(c->head_buf);
+    delete c;
+    h->tp = nullptr;
+}
+
+extern "C" {
+
+int mmada_comm_export_bytes(void) { return (int)sizeof(CommExport); }
+
+int mmada_comm_create(mmada_handle* h, int max_rows, void* export_out) {
+    if (!h || max_rows <= 0) return mm_fail("mmada_comm_create: bad argument");
+    if (h->cfg.tp_size < 2 || h->cfg.tp_size > TP_MAX) return mm_fail("mmada_comm_create: tp_size must be 2..%d", TP_MAX);
+    if (h->tp) tp_comm_free(h);
+    TpComm* c = new TpComm();
+    c->rank = h->cfg.tp_rank; c->size = h->cfg.tp_size; c->d = h->cfg.d_model;
+    c->max_rows = max_rows;
+    const size_t rows = (size_t)max_rows + 8 * c->size;
+    const size_t bytes = rows * c->d * 2;
+    MM_CHECK_HIP(hipMalloc(&c->part, bytes));
+    MM_CHECK_HIP(hipMalloc(&c->hn_pub, bytes));
+    MM_CHECK_HIP(hipMemset(c->part, 0, bytes));
+    MM_CHECK_HIP(hipMemset(c->hn_pub, 0, bytes));
+    // the counter peers poll must not be served from a stale cache line: fine-grained (coherent) device memory
+    if (hipExtMallocWithFlags((void**)&c->ctr, 64, hipDeviceMallocFinegrained) == hipSuccess) {
+        c->ctr_fine = true;
+    } else {
+        (void)hipGetLastError();
+        MM_CHECK_HIP(hipMalloc(&c->ctr, 64));
+    }
+    MM_CHECK_HIP(hipMemset(c->ctr, 0, 64));
+    MM_CHECK_HIP(hipMalloc(&c->seq, 64));
+    MM_CHECK_HIP(hipMemset(c->seq, 0, 64));
+    MM_CHECK_HIP(hipMalloc(&c->err, 64));
+    MM_CHECK_HIP(hipMemset(c->err, 0, 64));
+    MM_CHECK_HIP(hipMalloc(&c->rs_tmp, ((size_t)(max_rows + c->size - 1) / c->size + 16) * c->d * 2));
+    MM_CHECK_HIP(hipMalloc(&c->stats_pub, (size_t)STAT_ROWS * sizeof(TextStat)));
+    MM_CHECK_HIP(hipMemset(c->stats_pub, 0, (size_t)STAT_ROWS * sizeof(TextStat)));
+    MM_CHECK_HIP(hipMalloc(&c->stats_all, (size_t)c->size * STAT_ROWS * sizeof(TextStat)));
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);  // the exchange must not queue behind a whole round of GEMM workgroups
+    MM_CHECK_HIP(hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, hi));
+    for (int k = 0; k < 2; ++k) {
+        MM_CHECK_HIP(hipEventCreateWithFlags(&c->ev_g[k], hipEventDisableTiming));
+        MM_CHECK_HIP(hipEventCreateWithFlags(&c->ev_c[k], hipEventDisableTiming));
+    }
+    const char* e = getenv("MMADA_TP_CHUNKS");
+    c->chunks = e ? atoi(e) : 2;
+    MM_CHECK_HIP(hipDeviceSynchronize());
+    h->tp = c;
+    if (export_out) {
+        CommExport ex;
+        memset(&ex, 0, sizeof(ex));
+        hipError_t e1 = hipIpcGetMemHandle(&ex.part, c->part), e2 = hipIpcGetMemHandle(&ex.hn, c->hn_pub),
+                   e3 = hipIpcGetMemHandle(&ex.ctr, c->ctr);
+        if (e3 == hipSuccess) e3 = hipIpcGetMemHandle(&ex.stats, c->stats_pub);
+        if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+            (void)hipGetLastError();
+            memset(export_out, 0, sizeof(ex));
+            return mm_fail("mmada_comm_create: hipIpcGetMemHandle failed (%s): peers in other processes cannot map this rank; "
+                           "use mmada_comm_connect_rccl", hipGetErrorString(e1 != hipSuccess ? e1 : (e2 != hipSuccess ? e2 : e3)));
+        }
+        memcpy(export_out, &ex, sizeof(ex));
+    }
+    return 0;
+}
+
+int mmada_comm_connect_ipc(mmada_handle* h, const void* exports) {
+    if (!h || !h->tp || !exports) return mm_fail("mmada_comm_connect_ipc: call mmada_comm_create first");
+    TpComm* c = h->tp;
+    const CommExport* ex = (const CommExport*)exports;
+    for (int j = 0; j < c->size; ++j) {
+        if (j == c->rank) {
+            c->peers.part[j] = c->part; c->peers.hn[j] = c->hn_pub; c->peers.ctr[j] = c->ctr; c->peers.stats[j] = c->stats_pub;
+            continue;
+        }
+        void* p[4] = {nullptr, nullptr, nullptr, nullptr};
+        const hipIpcMemHandle_t* hd[4] = {&ex[j].part, &ex[j].hn, &ex[j].ctr, &ex[j].stats};
+        for (int b = 0; b < 4; ++b) {
+            hipError_t e = hipIpcOpenMemHandle(&p[b], *hd[b], hipIpcMemLazyEnablePeerAccess);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                return mm_fail("mmada_comm_connect_ipc: hipIpcOpenMemHandle(rank %d, buffer %d): %s", j, b, hipGetErrorString(e));
+            }
+            c->opened[b][j] = p[b];
+        }
+        c->peers.part[j] = (const bf16_t*)p[0]; c->peers.hn[j] = (const bf16_t*)p[1]; c->peers.ctr[j] = (const uint32_t*)p[2];
+        c->peers.stats[j] = (const TextStat*)p[3];
+    }
+    c->mode = 1;
+    return 0;
+}
+
+int mmada_comm_connect_local(mmada_handle* h, mmada_handle* const* ranks) {
+    if (!h || !h->tp || !ranks) return mm_fail("mmada_comm_connect_local: call mmada_comm_create first");
+    TpComm* c = h->tp;
+    for (int j = 0; j < c->size; ++j) {
+        if (!ranks[j] || !ranks[j]->tp) return mm_fail("mmada_comm_connect_local: rank %d has no comm", j);
+        if (ranks[j]->cfg.tp_rank != j) return mm_fail("mmada_comm_connect_local: handle %d is tp_rank %d", j, ranks[j]->cfg.tp_rank);
+        c->peers.part[j] = ranks[j]->tp->part; c->peers.hn[j] = ranks[j]->tp->hn_pub; c->peers.ctr[j] = ranks[j]->tp->ctr;
+        c->peers.stats[j] = ranks[j]->tp->stats_pub;
+    }
+    c->mode = 1;
+    return 0;
+}
+
+int mmada_comm_unique_id(void* out128, const char* librccl_path) {
+    if (!out128) return mm_fail("mmada_comm_unique_id: null argument");
+    static RcclApi api;
+    if (load_rccl(&api, librccl_path)) return 1;
+    ncclUniqueId id;
+    ncclResult_t r = api.GetUniqueId(&id);
+    if (r != ncclSuccess) return mm_fail("ncclGetUniqueId: %s", api.GetErrorString(r));
+    memcpy(out128, &id, sizeof(id));
+    return 0;
+}
+
+int mmada_comm_connect_rccl(mmada_handle* h, const void* unique_id128, const char* librccl_path) {
+    if (!h || !h->tp || !unique_id128) return mm_fail("mmada_comm_connect_rccl: call mmada_comm_create first");
+    TpComm* c = h->tp;
+    if (load_rccl(&c->nccl, librccl_path)) return 1;
+    ncclUniqueId id;
+    memcpy(&id, unique_id128, sizeof(id));
+    ncclResult_t r = c->nccl.CommInitRank(&c->comm, c->size, id, c->rank);
+    if (r != ncclSuccess) return nccl_fail(c, "ncclCommInitRank", r);
+    c->mode = 2;
+    return 0;
+}
+
+/* mode: 0 none, 1 pull (IPC / same-process peers), 2 RCCL.  err: != 0 after a hand-off timed out (synchronises `stream`). */
+int mmada_comm_status(mmada_handle* h, int* mode_out, int* err_out, int* finegrained_out, void* stream) {
+    if (!h) return mm_fail("mmada_comm_status: null handle");
+    if (mode_out) *mode_out = h->tp ? h->tp->mode : 0;
+    if (finegrained_out) *finegrained_out = h->tp ? (int)h->tp->ctr_fine : 0;
+    if (err_out) {
+        *err_out = 0;
+        if (h->tp) {
+            MM_CHECK_HIP(hipStreamSynchronize((hipStream_t)stream));
+            MM_CHECK_HIP(hipStreamSynchronize(h->tp->sc));
+            MM_CHECK_HIP(hipMemcpy(err_out, h->tp->err, sizeof(int), hipMemcpyDeviceToHost));
+        }
+    }
+    return 0;
+}
+
+int mmada_comm_set_mode(mmada_handle* h, int mode) {
+    if (!h || !h->tp) return mm_fail("mmada_comm_set_mode: no comm");
+    if (mode == 1 && !h->tp->peers.ctr[h->tp->size - 1 == h->tp->rank ? 0 : h->tp->size - 1])
+        return mm_fail("mmada_comm_set_mode: pull transport was never connected");
+    if (mode == 2 && !h->tp->comm) return mm_fail("mmada_comm_set_mode: RCCL transport was never connected");
+    h->tp->mode = mode;
+    return 0;
+}
+
+void* mmada_comm_part_ptr(mmada_handle* h) { return h && h->tp ? (void*)h->tp->part : nullptr; }
+
+/* One exchange over every row of the resident (B, L) carve, for probes and self-tests: the caller filled the partial
+ * buffer (mmada_comm_part_ptr, [B*Lp, d]) and the residual stream; afterwards x holds own rows + sum and xn (debug buffer
+ * 0) the RMSNorm of every row with norm_w (device bf16 [d]).  Runs on `stream` (no second stream, no chunking). */
+int mmada_comm_exchange(mmada_handle* h, const void* norm_w, void* stream) {
+    if (!h || !h->tp || h->M == 0 || !norm_w) return mm_fail("mmada_comm_exchange: need a comm and a resident carve (mmada_embed)");
+    const Slice sl = chunk_slice(h->M, h->tp->size, h->tp->rank, 1, 0);
+    if (h->tp->mode == 1) hipLaunchKernelGGL(tp_flush_kernel, dim3(256), dim3(64), 0, (hipStream_t)stream);
+    return exchange(h, sl, (const bf16_t*)norm_w, (hipStream_t)stream);
+}
+
+/* Vocabulary-parallel text step (generators/parallel_generator.py:185-217 at text_temperature == 0) after a
+ * tensor-parallel forward: this rank multiplies the ln_f rows by ITS slice of ff_out.weight (vocab / tp_size columns; the
+ * [B*T, vocab] logits exist nowhere), reduces each row to {max, first arg-max, fp64 sum-exp}, the tp records are exchanged
+ * (16 bytes per row and rank) and combined, and the k[b] most confident masked positions are committed on every rank.
+ * rows: device int32 [B*T] = b*L + text_start + t.  scratch: device, >= B*T*16 bytes (receives conf f64 / x0 i32). */
+int mmada_text_select_tp(mmada_handle* h, const int32_t* rows, int B, int T, int64_t* ids, int L, int text_start,
+                         const int32_t* k, void* scratch, void* stream) {
+    if (!h || !h->tp || h->tp->mode == 0) return mm_fail("mmada_text_select_tp: no tensor-parallel transport connected");
+    if (!h->xn_is_final || h->M == 0) return mm_fail("mmada_text_select_tp: no tensor-parallel forward resident");
+    if (!rows || !ids || !k || !scratch) return mm_fail("mmada_text_select_tp: null argument");
+    TpComm* c = h->tp;
+    const int R = B * T;
+    if (R <= 0) return 0;
+    if (R > STAT_ROWS || R > h->B * h->L) return mm_fail("mmada_text_select_tp: %d rows exceed the limit", R);
+    if (text_start < 0 || text_start + T > L) return mm_fail("mmada_text_select_tp: text span outside the sequence");
+    hipStream_t s = (hipStream_t)stream;
+    const int d = h->cfg.d_model, V = h->cfg.vocab;
+    const int w = ((V + c->size - 1) / c->size + 7) / 8 * 8;
+    const int v0 = min(V, c->rank * w), v1 = min(V, v0 + w);
+    const size_t need = (size_t)R * w * 2;
+    if (need > c->head_bytes) {  // first use (or a larger batch): not capturable, like every first call
+        (void)hipFree(c->head_buf);
+        c->head_buf = nullptr; c->head_bytes = 0;
+        MM_CHECK_HIP(hipMalloc(&c->head_buf, need));
+        c->head_bytes = need;
+    }
+    if (tp_head_gather(h, rows, R, s)) return 1;
+    if (v1 > v0) {
+        GemmArgs g{};
+        g.A = h->xg; g.W = h->lm_head + (size_t)v0 * d; g.C = c->head_buf;
+        g.M = R; g.N = v1 - v0; g.K = d; g.lda = d; g.ldw = d; g.ldc = w;
+        if (launch_gemm(EPI_STORE, g, s)) return 1;
+    }
+    if (launch_text_stats_partial(c->head_buf, B, T, v1 - v0, w, v0, ids, L, text_start, h->cfg.mask_token_id, c->stats_pub, s))
+        return 1;
+    double* conf = (double*)scratch;
+    int32_t* x0 = (int32_t*)((char*)scratch + (size_t)R * 8);
+    if (c->mode == 1) {
+        if (signal_wait(c, s)) return 1;
+        hipLaunchKernelGGL(tp_text_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, s, c->peers, c->size, c->rank,
+                           c->stats_pub, (const TextStat*)nullptr, 0, R, conf, x0);
+    } else {
+        ncclResult_t r = c->nccl.AllGather(c->stats_pub, c->stats_all, (size_t)R * sizeof(TextStat), ncclUint8, c->comm, s);
+        if (r != ncclSuccess) return nccl_fail(c, "ncclAllGather", r);
+        hipLaunchKernelGGL(tp_text_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, s, c->peers, c->size, c->rank,
+                           c->stats_pub, c->stats_all, R, R, conf, x0);
+    }
+    MM_CHECK_HIP(hipGetLastError());
+    return launch_text_commit(scratch, B, T, ids, L, text_start, k, s);
+}
+
+int mmada_comm_destroy(mmada_handle* h) {
+    if (h) tp_comm_free(h);
+    return 0;
+}
+
+}  // extern "C"
+
+int tp_head_gather(mmada_handle* h, const int32_t* rows, int R, hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, s, h->xn, rows, R, h->L, h->Lp, h->cfg.d_model,
+                       h->B * h->L, h->xg);
+    MM_CHECK_HIP(hipGetLastError());
+    return 0;
+}

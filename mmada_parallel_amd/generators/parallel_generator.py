@@ -183,7 +183,8 @@ def _ti2ti_steps(
     CBs = codebook_size
     k_cur = torch.zeros(B, dtype=torch.int32, device=device)
     mlen_cur = torch.zeros(1, dtype=torch.int32, device=device)
-    text_logits = torch.empty((B * T, V), dtype=torch.bfloat16, device=device)
+    vp_text = text_temperature == 0 and model.vocab_parallel_head()  # the [B*T, V] logits are then never materialised
+    text_logits = None if vp_text else torch.empty((B * T, V), dtype=torch.bfloat16, device=device)
     cond_vq = torch.empty((B * N, CBs), dtype=torch.bfloat16, device=device) if img_steps else None
     unc = torch.empty((2 * B, L), dtype=torch.long, device=device) if need_uncond else None
     unc_vq = torch.empty((2 * B * N, CBs), dtype=torch.bfloat16, device=device) if need_uncond and img_steps else None
@@ -206,7 +207,12 @@ def _ti2ti_steps(
         st = abi.stream_ptr()
         if is_img:
             model.head_rows(img_rows_1, text_vocab_size, text_vocab_size + codebook_size, out=cond_vq)
-        if need_text:
+        if need_text and vp_text:
+            # tensor parallel: each rank holds vocab/tp columns of the LM head; rows are reduced to {max, arg-max, sum-exp}
+            # and only those 16 bytes per row travel (mmada_text_select_tp) — the [B*T, V] logits exist on no rank
+            abi.check(lib.mmada_text_select_tp(h, text_rows.data_ptr(), B, T, ids.data_ptr(), L, text_start,
+                                               k_cur.data_ptr(), scratch.data_ptr(), st), "mmada_text_select_tp")
+        elif need_text:
             model.head_rows(text_rows, 0, V, out=text_logits)  # [B*T, V]
             noisy = None
             if text_temperature != 0:

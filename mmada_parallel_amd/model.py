@@ -99,6 +99,7 @@ class LLaDAForMultiModalGeneration:
         self._ws1 = None
         self._ws_bytes = [0, 0]  # bytes registered with the library per activation context
         self.graph_replays, self.graph_nodes = 0, {}  # hipGraph step replays issued / nodes per captured step kind
+        self._comm_in_library, self._comm_rows, self.tp_collective = False, 0, None
         self._handle1 = None
         self._split = None
         self.n_kv_heads = effective_n_kv_heads(config)
@@ -219,7 +220,8 @@ class LLaDAForMultiModalGeneration:
         ids = input_ids.to(device=self.device, dtype=torch.long).contiguous()
         B, L = ids.shape
         st = abi.stream_ptr()
-        microbatch = B >= 2 and (self.tp_size > 1 or os.environ.get("MMADA_MICROBATCH") == "1")
+        in_lib = self.tp_size > 1 and self._comm_in_library
+        microbatch = B >= 2 and not in_lib and (self.tp_size > 1 or os.environ.get("MMADA_MICROBATCH") == "1")
         self._split = None
         lo, hi = (int(consumed[0]), int(consumed[1])) if consumed is not None else (0, 0)
         if consumed is not None and not 0 <= lo < hi <= L:
@@ -229,7 +231,10 @@ class LLaDAForMultiModalGeneration:
             abi.check(self._lib.mmada_set_consumed_rows(self._lane_handle(lane), lo, hi), "mmada_set_consumed_rows")
         if not microbatch:
             self._ensure_ws(B, L)
-            if self.tp_size == 1:
+            if self.tp_size == 1 or in_lib:
+                # tp_size > 1: the reduce-scatter / RMSNorm / all-gather exchanges are issued by the library (tp_comm.hip)
+                if in_lib and B * ((L + 7) // 8 * 8) > self._comm_rows:
+                    raise abi.MmadaError(f"forward of {B}x{L} exceeds the {self._comm_rows} rows init_tp_comm() was sized for")
                 abi.check(self._lib.mmada_forward_body(self._handle, ids.data_ptr(), B, L, st), "mmada_forward_body")
             else:
                 import torch.distributed as dist
@@ -348,6 +353,149 @@ class LLaDAForMultiModalGeneration:
         return CausalLMOutputLite(logits=logits)
 
     __call__ = forward
+
+    # ---- tensor-parallel transport (csrc/tp_comm.hip) ---------------------------------------------------------------
+    class _DevView:
+        """Zero-copy torch view of library-owned device memory (__cuda_array_interface__)."""
+
+        def __init__(self, ptr, n_u16):
+            self.__cuda_array_interface__ = {"shape": (n_u16,), "typestr": "<u2", "data": (ptr, False), "version": 2}
+
+    def _part_view(self, rows: int) -> torch.Tensor:
+        ptr = self._lib.mmada_comm_part_ptr(self._handle)
+        n = rows * self.config.d_model
+        return torch.as_tensor(self._DevView(ptr, n), device=self.device).view(torch.bfloat16).view(rows, self.config.d_model)
+
+    def comm_status(self):
+        mode, err, fine = C.c_int(), C.c_int(), C.c_int()
+        abi.check(self._lib.mmada_comm_status(self._handle, C.byref(mode), C.byref(err), C.byref(fine), abi.stream_ptr()),
+                  "mmada_comm_status")
+        return {"mode": {0: "none", 1: "pull", 2: "rccl"}[mode.value], "error": err.value, "finegrained_counters": bool(fine.value)}
+
+    def comm_selftest(self, iters: int = 3, L: int = 96) -> bool:
+        """`iters` exchanges over a small carve with known partials (different data every round, so a stale cache line
+        cannot pass): every row of the all-gathered, normalised result must equal the locally computed expectation bit for
+        bit.  Every rank must call it; returns this rank's verdict."""
+        d, tp, r = self.config.d_model, self.tp_size, self.tp_rank
+        B = 2
+        ids = (torch.arange(B * L, device=self.device).view(B, L) * 7 + 3) % 1000
+        Lp = (L + 7) // 8 * 8
+        M = B * Lp
+        self._ensure_ws(B, L)
+        w = torch.ones(d, dtype=torch.bfloat16, device=self.device)
+        part = self._part_view(M)
+        st = abi.stream_ptr()
+        ok = True
+        col = torch.arange(d, device=self.device, dtype=torch.float32)[None, :]
+        row = torch.arange(M, device=self.device, dtype=torch.float32)[:, None]
+        for it in range(iters):
+            abi.check(self._lib.mmada_embed(self._handle, ids.data_ptr(), B, L, st), "mmada_embed")
+            self._shape, self._split = (B, L), None
+            x0 = self._stream_view().view(M, d).clone()
+
+            def pat(rank):  # small integers: exact in bf16, different per rank / row / column / round
+                return (((row * 3 + col * 5 + rank * 11 + it * 17) % 13) - 6.0) * (rank + 1)
+
+            part.copy_(pat(r).to(torch.bfloat16))
+            abi.check(self._lib.mmada_comm_exchange(self._handle, w.data_ptr(), st), "mmada_comm_exchange")
+            total = sum(pat(j).to(torch.bfloat16).float() for j in range(tp))
+            x_new = (x0.float() + total.to(torch.bfloat16).float()).to(torch.bfloat16)
+            want = torch.empty_like(x_new)
+            abi.check(self._lib.mmada_rmsnorm(x_new.data_ptr(), w.data_ptr(), want.data_ptr(), M, d,
+                                              float(self.config.ref("rms_norm_eps")), st), "mmada_rmsnorm")
+            got = self.debug_buffer(0).view(-1, d)[:M]
+            ok = ok and bool(torch.equal(got, want))
+        return ok and self.comm_status()["error"] == 0
+
+    def init_tp_comm(self, max_batch: int, max_len: int, group=None, transport: str = "auto") -> str:
+        """Connect the library's tensor-parallel exchange over the ranks of `group` (a torch.distributed group: control
+        plane only — handles / unique id are exchanged as objects; the data path never goes through torch).
+        transport: "pull" (mapped peer buffers, hipIpc), "rccl", or "auto" = pull if it connects AND passes the self-test
+        on every rank, else RCCL, else the host-issued all-reduce of the segment API.  Returns what is in use."""
+        import torch.distributed as dist
+
+        lib = self._lib
+        rows = max_batch * ((max_len + 7) // 8 * 8)
+        nb = lib.mmada_comm_export_bytes()
+        buf = C.create_string_buffer(nb)
+        exported = lib.mmada_comm_create(self._handle, rows, buf) == 0
+        if not exported:
+            abi.check(lib.mmada_comm_create(self._handle, rows, None), "mmada_comm_create")
+        self._comm_rows = rows
+
+        def all_agree(flag: bool) -> bool:
+            got = [None] * self.tp_size
+            dist.all_gather_object(got, bool(flag), group=group)
+            return all(got)
+
+        chosen = None
+        if transport in ("auto", "pull"):
+            blobs = [None] * self.tp_size
+            dist.all_gather_object(blobs, buf.raw if exported else None, group=group)
+            ok = exported and all(b is not None for b in blobs)
+            if ok:
+                ok = lib.mmada_comm_connect_ipc(self._handle, b"".join(blobs)) == 0
+            ok = all_agree(ok)
+            if ok:
+                self._comm_in_library = True
+                ok = all_agree(self.comm_selftest())
+            if ok:
+                chosen = "pull"
+            elif transport == "pull":
+                raise abi.MmadaError("tensor-parallel pull transport failed to connect or failed its self-test: "
+                                     + (lib.mmada_last_error() or b"").decode())
+        if chosen is None and transport in ("auto", "rccl"):
+            backend_ok = dist.get_backend(group) == "nccl"  # one rank per device: RCCL refuses two ranks on one GPU
+            if all_agree(backend_ok):
+                path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()
+                uid = C.create_string_buffer(128)
+                if self.tp_rank == 0:
+                    abi.check(lib.mmada_comm_unique_id(uid, path), "mmada_comm_unique_id")
+                box = [uid.raw]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                ok = lib.mmada_comm_connect_rccl(self._handle, box[0], path) == 0
+                if all_agree(ok):
+                    self._comm_in_library = True
+                    if all_agree(self.comm_selftest()):
+                        chosen = "rccl"
+            if chosen is None and transport == "rccl":
+                raise abi.MmadaError("tensor-parallel RCCL transport failed: " + (lib.mmada_last_error() or b"").decode())
+        if chosen is None:
+            self._comm_in_library = False
+            lib.mmada_comm_destroy(self._handle)
+            chosen = "host all-reduce (torch.distributed)"
+        self.tp_collective = chosen
+        return chosen
+
+    def collective_probe(self, L: int, B: int = 1, iters: int = 10):
+        """Outside any timed region: one exchange (reduce-scatter + RMSNorm + all-gather of B*L rows x d bf16) timed alone,
+        so a scaling run also records what the fabric delivered for the message size the forward uses."""
+        if not self._comm_in_library:
+            return None
+        import time
+
+        ids = torch.zeros((B, L), dtype=torch.long, device=self.device)
+        self._ensure_ws(B, L)
+        st = abi.stream_ptr()
+        abi.check(self._lib.mmada_embed(self._handle, ids.data_ptr(), B, L, st), "mmada_embed")
+        w = torch.ones(self.config.d_model, dtype=torch.bfloat16, device=self.device)
+        for _ in range(3):
+            abi.check(self._lib.mmada_comm_exchange(self._handle, w.data_ptr(), st), "mmada_comm_exchange")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            abi.check(self._lib.mmada_comm_exchange(self._handle, w.data_ptr(), st), "mmada_comm_exchange")
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / iters * 1e3
+        nbytes = B * ((L + 7) // 8 * 8) * self.config.d_model * 2
+        tp = self.tp_size
+        return {"transport": self.tp_collective, "rows": B * L, "bytes": nbytes, "ms": ms,
+                "busbw_GBps": 2.0 * (tp - 1) / tp * nbytes / (ms * 1e-3) / 1e9, "exchanges_per_forward": 2 * self.config.n_layers,
+                "status": self.comm_status()}
+
+    def vocab_parallel_head(self) -> bool:
+        """True when the text step can run on vocabulary slices of the LM head (library transport connected)."""
+        return self._comm_in_library and os.environ.get("MMADA_TP_REPLICATED_HEAD") != "1"
 
     def graph_capturable(self) -> bool:
         """True when forward_body / head_rows issue only stream launches (no host-side collective): the sampler may then

@@ -639,6 +639,11 @@ def test_bench_multi_rank_tensor_parallel_on_one_gpu(world):
     assert out["n_gpus"] == world and out["config"]["parallelism"] == f"tp{world}" and out["config"]["global_batch"] == world
     assert out["config"]["tp_ranks_agree"] is True
     assert out["value"] > 0 and "REDUCED" in out["config"]["workload"]
+    # the exchange ran inside the library over hipIpc-mapped peer buffers (gloo only carried the handles), passed its
+    # self-test on every rank, and no hand-off timed out
+    assert out["config"]["tp_collective"] == "pull", out["config"]["tp_collective"]
+    probe = out["config"]["allreduce_probe"]
+    assert probe and probe["status"]["error"] == 0 and probe["status"]["mode"] == "pull"
 
 
 # ------------------------------------------------------------------------------- consumed-row window of the last block
