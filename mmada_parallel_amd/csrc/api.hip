@@ -177,7 +177,9 @@ int mmada_embed(mmada_handle* h, const int64_t* ids, int B, int L, void* stream)
     if (apply_carve(h, B, L, s)) return 1;
     h->cur_W = 0; h->cur_beg = 0; h->Mcur = h->M;
     h->xn_is_final = false;
-    return launch_embed(ids, h->wte, h->x, B, L, h->Lp, h->cfg.d_model, h->cfg.vocab, s);
+    h->xn_is_layer0 = true;
+    return launch_embed(ids, h->wte, h->x, B, L, h->Lp, h->cfg.d_model, h->cfg.vocab, s, h->layers[0].attn_norm, h->xn,
+                        h->cfg.rms_eps);
 }
 
 int mmada_attn_partial(mmada_handle* h, int layer, void* stream) {
@@ -186,7 +188,9 @@ int mmada_attn_partial(mmada_handle* h, int layer, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const LayerWeights& lw = h->layers[layer];
     const int d = h->cfg.d_model;
-    if (launch_rmsnorm(h->x, lw.attn_norm, h->xn, h->M, d, h->cfg.rms_eps, s)) return 1;
+    if (layer == 0 && h->xn_is_layer0) {
+        h->xn_is_layer0 = false;  // the embedding kernel normalised its rows already
+    } else if (launch_rmsnorm(h->x, lw.attn_norm, h->xn, h->M, d, h->cfg.rms_eps, s)) return 1;
     GemmArgs g{};
     g.A = h->xn; g.W = lw.wqkv; g.C = nullptr;
     g.M = h->M; g.N = (h->hq_l + 2 * h->hkv_l) * 128; g.K = d;

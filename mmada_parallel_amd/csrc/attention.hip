@@ -52,6 +52,7 @@ struct AttnArgs {
     int Hq, Hkv, L, Lq_rows, Lkv, out_rows_per_batch, ld_out;
     int q_begin;  // first query row (multiple of 32); output row of query r is b*out_rows_per_batch + r - q_begin
     float scale_log2e;
+    int xcd_pairs, nq;  // XCD-aware 1-D grid: (batch, head) pairs per XCD and query tiles per pair (0: plain 3-D grid)
 };
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
@@ -59,7 +60,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hi = lane >> 5;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
+    // Workgroup -> (query tile, head, batch).  With xcd_pairs > 0 the grid is 1-D and XCD-aware: hardware workgroup ids
+    // round-robin over the 8 XCDs (observed, speed only), so XCD x takes the (batch, head) pairs [x*xcd_pairs, (x+1)*
+    // xcd_pairs) and all their query tiles — a head's K / vT (1.25 MB at L = 2438) is then fetched into ONE private L2
+    // instead of all eight.
+    int qb, h, b;
+    if (a.xcd_pairs > 0) {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int pair = xcd * a.xcd_pairs + i / a.nq;
+        qb = i - (i / a.nq) * a.nq;
+        b = pair / a.Hq;
+        h = pair - b * a.Hq;
+    } else {
+        qb = blockIdx.x; h = blockIdx.y; b = blockIdx.z;
+    }
     const int hkv = h / (a.Hq / a.Hkv);
     const bf16_t* Qp = a.q + (size_t)(b * a.Hq + h) * a.Lkv * 128;
     const bf16_t* Kp = a.k + (size_t)(b * a.Hkv + hkv) * a.Lkv * 128;
@@ -202,175 +216,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
 }
 
-// Three workgroups per CU (12 waves, 3 per SIMD): 640 workgroups of a batch-1 forward (20 query tiles x 32 heads) fit the
-// 768 slots in ONE round instead of 1.25 rounds of 512, and a third wave per SIMD fills MFMA slots the other two leave
-// idle during their soft-max.  Needs <= 168 VGPRs (launch bound) and <= 53 KiB of LDS: the K and vT tiles go through a
-// ring of THREE 16-KiB slots (item 2t = K_t, item 2t+1 = vT_t, item i in slot i % 3) with one barrier before each of the
-// two matrix phases; every tile is still requested two phases before it is read.
-__global__ __launch_bounds__(256, 3) void attn_fwd3_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int ql = lane & 31, hi = lane >> 5;
-    const int qb = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
-    const int hkv = h / (a.Hq / a.Hkv);
-    const bf16_t* Qp = a.q + (size_t)(b * a.Hq + h) * a.Lkv * 128;
-    const bf16_t* Kp = a.k + (size_t)(b * a.Hkv + hkv) * a.Lkv * 128;
-    const bf16_t* Vp = a.vT + (size_t)(b * a.Hkv + hkv) * 128 * a.Lkv;
-
-    const int q_row = a.q_begin + qb * QB + wave * 32 + ql;
-    const int q_ld = min(q_row, a.Lkv - 1);
-    bf16x8 qf[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) qf[s] = *(const bf16x8*)(Qp + (size_t)q_ld * 128 + s * 16 + hi * 8);
-
-    f32x16 o[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;  // m_run in scaled log2 units
-
-    // LDS-DMA sources: wave w moves K pieces 4w..4w+3 (4 rows x 256 B each) and vT pieces 4w..4w+3 (8 rows x 128 B)
-    // byte offsets (unsigned 32-bit) from a wave-uniform tile base: the loads take the scalar-base + vector-offset form,
-    // so advancing to the next tile is two scalar adds instead of eight 64-bit vector adds
-    unsigned koff[4], voff[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int kr = (wave * 4 + i) * 4 + (lane >> 4);
-        koff[i] = (unsigned)(kr * 128 + (((lane & 15) ^ (kr & 15)) << 3)) * 2u;
-        const int d = (wave * 4 + i) * 8 + (lane >> 3);
-        voff[i] = (unsigned)(d * a.Lkv + (((lane & 7) ^ ((d >> 1) & 7)) << 3)) * 2u;
-    }
-    auto stage_k = [&](int slot, int kt) {
-        char* base = smem + slot * TILE_BYTES + wave * 4096;
-        const char* kb = (const char*)Kp + (size_t)kt * KB * 256;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(kb + koff[i]), (lptr_t)(base + i * 1024), 16, 0, 0);
-    };
-    auto stage_v = [&](int slot, int kt) {
-        char* base = smem + slot * TILE_BYTES + wave * 4096;
-        const char* vb = (const char*)Vp + (size_t)kt * KB * 2;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((gptr_t)(vb + voff[i]), (lptr_t)(base + i * 1024), 16, 0, 0);
-    };
-
-    const int nkt = (a.L + KB - 1) / KB;
-    const int ksw = ql & 15, vsw = (ql >> 1) & 7;
-    stage_k(0, 0);
-    stage_v(1, 0);
-    int slot_k = 0;  // slot of item 2*kt; item 2*kt+1 (vT) sits in the next slot, item 2*kt+2 (next K) in the one after
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int slot_v = slot_k == 2 ? 0 : slot_k + 1, slot_n = slot_v == 2 ? 0 : slot_v + 1;
-        // K_kt has landed (the 4 vT pieces requested after it may still be in flight); every wave is past PV(kt-1)
-        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        if (kt + 1 < nkt) stage_k(slot_n, kt + 1);
-        const char* Kt = smem + slot_k * TILE_BYTES;
-        const char* Vt = smem + slot_v * TILE_BYTES;
-
-        // ---- S^T = K · Q^T for keys [0,32) and [32,64) of the tile ----
-        f32x16 s0, s1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const int ch = ((2 * s + hi) ^ ksw) << 4;
-            const bf16x8 ka0 = *(const bf16x8*)(Kt + ql * 256 + ch);
-            const bf16x8 ka1 = *(const bf16x8*)(Kt + (32 + ql) * 256 + ch);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qf[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qf[s], s1, 0, 0, 0);
-        }
-        // keys past L (only in the last tile) get -inf; select, not arithmetic, so garbage K rows cannot leak NaN
-        if (kt * KB + KB > a.L) {
-            const int kbase = kt * KB + 4 * hi;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kbase + (r & 3) + 8 * (r >> 2);
-                if (key >= a.L) s0[r] = -INFINITY;
-                if (key + 32 >= a.L) s1[r] = -INFINITY;
-            }
-        }
-        // ---- online softmax (fp32, log2 domain); lane and lane^32 share a query ----
-        float mxa = fmax_nc(s0[0], s1[0]), mxb = fmax_nc(s0[1], s1[1]);  // two chains: shorter dependency depth
-#pragma unroll
-        for (int r = 2; r < 16; r += 2) {
-            mxa = max3f(mxa, s0[r], s1[r]);
-            mxb = max3f(mxb, s0[r + 1], s1[r + 1]);
-        }
-        float mx = fmax_nc(mxa, mxb);
-        mx = fmax_nc(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2e;
-        if (!__all(mx - m_run <= DEFER_LOG2)) {  // wave-uniform: rescale only when some row's max really grew
-            const float m_new = fmax_nc(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-            l_run *= alpha;
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-            m_run = m_new;
-        }
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(s0[r] * a.scale_log2e - m_run);
-            s1[r] = __builtin_amdgcn_exp2f(s1[r] * a.scale_log2e - m_run);
-            psum += s0[r] + s1[r];
-        }
-        l_run += psum;
-
-        // P -> bf16 B-operand fragments: pb[t][s2] = P[q][keys of accumulator regs 8*s2 .. 8*s2+7 of tile t]
-        bf16x8 pb[2][2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                pb[0][s2][j] = (__bf16)s0[8 * s2 + j];
-                pb[1][s2][j] = (__bf16)s1[8 * s2 + j];
-            }
-
-        // vT_kt has landed (K_kt+1, if requested, may still be in flight); every wave is past QK(kt): its slot is free
-        if (kt + 1 < nkt) {
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            stage_v(slot_k, kt + 1);
-        } else {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-        }
-        // ---- O^T += V^T · P^T ----
-#pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            const char* vrow = Vt + (db * 32 + ql) * 128;  // swizzle of row db*32+ql does not depend on db
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 va = *(const bf16x8*)(vrow + (((4 * t + 2 * s2 + hi) ^ vsw) << 4));
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[t][s2], o[db], 0, 0, 0);
-                }
-        }
-        slot_k = slot_n;
-    }
-
-    // ---- normalise and store: lane holds O[q_row][d = db*32 + 8g + 4hi + j] ----
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (q_row < a.Lq_rows) {
-        bf16_t* orow = a.out + ((size_t)b * a.out_rows_per_batch + q_row - a.q_begin) * a.ld_out + h * 128;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                u32x2 pk;
-                pk[0] = pack_bf2(o[db][4 * g4 + 0] * inv, o[db][4 * g4 + 1] * inv);
-                pk[1] = pack_bf2(o[db][4 * g4 + 2] * inv, o[db][4 * g4 + 3] * inv);
-                *(u32x2*)(orow + db * 32 + 8 * g4 + 4 * hi) = pk;
-            }
-    }
-}
-
-
 }  // namespace
 
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int B, int Hq, int Hkv, int L,
@@ -382,24 +227,22 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     static bool attr_set = false;
     if (!attr_set) {
         MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
-        MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * TILE_BYTES));
         attr_set = true;
     }
-    // MMADA_ATTN_WGS=2|3: workgroups per CU (2: 64 KiB double-buffered K+vT, 207 VGPRs; 3: 48 KiB ring, 168 VGPRs)
-    static const int wgs = [] {
-        const char* e = getenv("MMADA_ATTN_WGS");
-        return e ? atoi(e) : 2;
-    }();
     AttnArgs a;
     a.q = q; a.k = k; a.vT = vT; a.out = out;
     a.Hq = Hq; a.Hkv = Hkv; a.L = L; a.Lq_rows = Lq_rows; a.Lkv = Lkv;
     a.out_rows_per_batch = out_rows_per_batch; a.ld_out = ld_out; a.q_begin = q_begin;
     a.scale_log2e = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
-    const dim3 grid((Lq_rows - q_begin + QB - 1) / QB, Hq, B);
-    if (wgs == 3)
-        hipLaunchKernelGGL(attn_fwd3_kernel, grid, dim3(256), 3 * TILE_BYTES, s, a);
-    else
-        hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), ATT_LDS, s, a);
+    const int nq = (Lq_rows - q_begin + QB - 1) / QB, pairs = Hq * B;
+    static const bool xcd_aware = [] { const char* e = getenv("MMADA_ATTN_XCD"); return !(e && e[0] == '0'); }();
+    if (xcd_aware && pairs % 8 == 0) {
+        a.xcd_pairs = pairs / 8; a.nq = nq;
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3(nq * pairs), dim3(256), ATT_LDS, s, a);
+    } else {
+        a.xcd_pairs = 0; a.nq = nq;
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3(nq, Hq, B), dim3(256), ATT_LDS, s, a);
+    }
     MM_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -4,25 +4,6 @@
 
 namespace {
 
-// ---- embedding gather: x[b*Lp + l] = wte[ids[b*L + l]] (model/modeling_llada.py:1265), pad rows zero ----------
-__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ wte,
-                                                    bf16_t* __restrict__ x, int B, int L, int Lp, int d, int vocab) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= B * Lp) return;
-    const int b = row / Lp, l = row - b * Lp;
-    u32x4* dst = (u32x4*)(x + (size_t)row * d);
-    const int nchunk = d >> 3;
-    if (l < L) {
-        long long id = ids[(size_t)b * L + l];
-        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // torch would raise; clamp keeps the device safe
-        const u32x4* src = (const u32x4*)(wte + (size_t)id * d);
-        for (int c = lane; c < nchunk; c += 64) dst[c] = src[c];
-    } else {
-        for (int c = lane; c < nchunk; c += 64) dst[c] = u32x4{0, 0, 0, 0};
-    }
-}
-
 // ---- RMSLayerNorm.forward (model/modeling_llada.py:315-329) ------------------------------------------------------
 //   x32 = x.float(); var = mean(x32^2); y = bf16(x32 * rsqrt(var + eps)); out = bf16(w * y)   (cast-then-scale)
 MM_DEVICE void rmsnorm_row(const bf16_t* __restrict__ xr, const bf16_t* __restrict__ w, bf16_t* __restrict__ outr,
@@ -87,6 +68,35 @@ MM_DEVICE void rmsnorm_row_regs(const bf16_t* __restrict__ xr, const bf16_t* __r
             o[j] = pack_bf2(wl * bfround(lo * rs), wh * bfround(hi * rs));
         }
         ((u32x4*)outr)[lane + 64 * i] = o;
+    }
+}
+
+// ---- embedding gather: x[b*Lp + l] = wte[ids[b*L + l]] (model/modeling_llada.py:1265), pad rows zero ----------
+// Fused with the first RMSNorm of the forward (block 0's attn_norm, :924): the wave that gathered the row normalises it
+// while it is still in L1 — same row routine as rmsnorm_kernel, hence the same bits.
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ ids, const bf16_t* __restrict__ wte,
+                                                    bf16_t* __restrict__ x, int B, int L, int Lp, int d, int vocab,
+                                                    const bf16_t* __restrict__ norm_w, bf16_t* __restrict__ xn, float eps) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= B * Lp) return;
+    const int b = row / Lp, l = row - b * Lp;
+    u32x4* dst = (u32x4*)(x + (size_t)row * d);
+    const int nchunk = d >> 3;
+    if (l < L) {
+        long long id = ids[(size_t)b * L + l];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // torch would raise; clamp keeps the device safe
+        const u32x4* src = (const u32x4*)(wte + (size_t)id * d);
+        for (int c = lane; c < nchunk; c += 64) dst[c] = src[c];
+    } else {
+        for (int c = lane; c < nchunk; c += 64) dst[c] = u32x4{0, 0, 0, 0};
+    }
+    if (norm_w) {  // every lane re-reads exactly the chunks it wrote
+        __threadfence_block();
+        if (d == 4096)
+            rmsnorm_row_regs<8>(x + (size_t)row * d, norm_w, xn + (size_t)row * d, eps, lane);
+        else
+            rmsnorm_row(x + (size_t)row * d, norm_w, xn + (size_t)row * d, d, eps, lane);
     }
 }
 
@@ -247,8 +257,9 @@ __global__ void lfq_gather_kernel(const int64_t* __restrict__ idx, void* __restr
     MM_CHECK_HIP(hipGetLastError()); \
     return 0
 
-int launch_embed(const int64_t* ids, const bf16_t* wte, bf16_t* x, int B, int L, int Lp, int d, int vocab, hipStream_t s) {
-    hipLaunchKernelGGL(embed_kernel, dim3((B * Lp + 3) / 4), dim3(256), 0, s, ids, wte, x, B, L, Lp, d, vocab);
+int launch_embed(const int64_t* ids, const bf16_t* wte, bf16_t* x, int B, int L, int Lp, int d, int vocab, hipStream_t s,
+                 const bf16_t* norm_w, bf16_t* xn, float eps) {
+    hipLaunchKernelGGL(embed_kernel, dim3((B * Lp + 3) / 4), dim3(256), 0, s, ids, wte, x, B, L, Lp, d, vocab, norm_w, xn, eps);
     LAUNCH_CHECK();
 }
 int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int d, float eps, hipStream_t s) {

@@ -11,7 +11,7 @@
 //     bank-conflict swizzle (16-B chunk c -> c ^ ((row>>1)&7) inside each 128-B row) is applied to the per-lane
 //     SOURCE address and to the ds_read address (guide rule 21); reads are conflict-free.
 //   * two LDS stages, one raw s_barrier per K-tile: wait(tile t landed) ; barrier ; issue tile t+1 ; multiply t.
-//   * BM is chosen per launch from {128,160,192,224,256} so that the tile grid fills the 256 CUs with the fewest
+//   * BM is chosen per launch from {128,160,192,224,256,320} so that the tile grid fills the 256 CUs with the fewest
 //     row-waves (M = 2438 x N = 4096 is 160 tiles of 256x256 — 62 % of the CUs — but exactly 256 tiles of 160x256).
 //   * workgroup ids are remapped XCD-aware and in grouped order so each private L2 sees a compact patch of tiles.
 //
@@ -312,19 +312,26 @@ int launch_cfg(const GemmArgs& g, hipStream_t s) {
 // plus pipeline fill and the BM x 256 output tile's HBM traffic, which nothing overlaps at one workgroup per CU).
 // Constants are a least-squares fit (rms 6 %) to tools/bm_sweep.sh on MI355X: 240 (shape, M, BM) timings over
 // K = 512..6144, N = 768..6144, M = 2440..19520; choosing by it is within 0.3 % of the best BM on that set.
+// per-row cost of the 320-row tile relative to 256: fitted to tools/gemm_sweep.py on MI355X (round 2: 0.96-1.02 over
+// gate/up, qkv, attn_out and down at M = 2438 / 4876)
+constexpr float H320 = 1.0f;
+
 int pick_bm(int M, int N, int K) {
     static const int forced = [] {  // MMADA_GEMM_BM=<128|160|192|224|256>: tests / sweeps force one configuration
         const char* e = getenv("MMADA_GEMM_BM");
         return e ? atoi(e) : 0;
     }();
-    if (forced == 128 || forced == 160 || forced == 192 || forced == 224 || forced == 256) return forced;
-    const int cand[5] = {256, 224, 192, 160, 128};
-    const float h[5] = {1.0f, 1.096f, 1.125f, 1.277f, 1.236f};
+    if (forced == 128 || forced == 160 || forced == 192 || forced == 224 || forced == 256 || forced == 320) return forced;
+    // 320 x 256 (80 x 64 per wave, 2 stages = 144 KiB of LDS, 117 VGPRs): M = 2440 x N = 24576 is 768 tiles = exactly 3
+    // rounds instead of 3.75 -> 4 rounds of 256-row tiles; M = 4880 x N = 4096 is 256 tiles = one round
+    static const bool no320 = [] { const char* e = getenv("MMADA_GEMM_NO320"); return e && e[0] == '1'; }();
+    const int cand[6] = {320, 256, 224, 192, 160, 128};
+    const float h[6] = {H320, 1.0f, 1.096f, 1.125f, 1.277f, 1.236f};
     const float A = 0.00549f, C0 = 2.665f, C1 = 0.03107f;
     const int ntn = (N + BN - 1) / BN, nk = K / BK;
     int best = 256;
     float best_cost = 1e30f;
-    for (int i = 0; i < 5; ++i) {
+    for (int i = no320 ? 1 : 0; i < 6; ++i) {
         const int bm = cand[i];
         const int tiles = ((M + bm - 1) / bm) * ntn;
         const float cost = (float)((tiles + 255) / 256) * (A * bm * nk * h[i] + C0 + C1 * bm);
@@ -336,6 +343,7 @@ int pick_bm(int M, int N, int K) {
 template <int EPI>
 int launch_t(const GemmArgs& g, hipStream_t s) {
     switch (pick_bm(g.M, g.N, g.K)) {
+        case 320: return launch_cfg<EPI, 320, 4, 4>(g, s);
         case 256: return launch_cfg<EPI, 256, 4, 4>(g, s);
         case 192: return launch_cfg<EPI, 192, 4, 4>(g, s);
         case 128: return launch_cfg<EPI, 128, 4, 4>(g, s);

@@ -49,6 +49,7 @@ struct mmada_handle {
     // ln_f(x) for every row (the last reduce-scatter of a tensor-parallel forward applies ln_f on the owned rows)
     TpComm* tp = nullptr;
     bool xn_is_final = false;
+    bool xn_is_layer0 = false;  // mmada_embed already wrote xn = RMSNorm(x) * blocks[0].attn_norm (fused, K1)
 };
 
 // tp_comm.hip

@@ -38,7 +38,9 @@ struct GemmArgs {
 int launch_gemm(int epi, const GemmArgs& g, hipStream_t s);
 
 // elementwise.hip
-int launch_embed(const int64_t* ids, const bf16_t* wte, bf16_t* x, int B, int L, int Lp, int d, int vocab, hipStream_t s);
+// norm_w != null: also xn = RMSNorm(x) * norm_w (the first norm of the forward, fused: SURVEY §2.3 K1)
+int launch_embed(const int64_t* ids, const bf16_t* wte, bf16_t* x, int B, int L, int Lp, int d, int vocab, hipStream_t s,
+                 const bf16_t* norm_w = nullptr, bf16_t* xn = nullptr, float eps = 0.f);
 int launch_rmsnorm(const bf16_t* x, const bf16_t* w, bf16_t* out, int rows, int d, float eps, hipStream_t s);
 // gathered rmsnorm: out[r] = rmsnorm(x[map(rows[r])]) where rows[r] = b*L + l and x rows are b*Lp + l
 // x row of the flat index b*L + l is b*row_stride + l - row_off (row_stride = Lp, row_off = 0 for the full layout)

@@ -70,7 +70,7 @@ struct TpComm {
     size_t head_bytes = 0;
     uint32_t* seq = nullptr;   // [1]  private: number of hand-offs this rank has published
     int* err = nullptr;        // [1]  private: != 0 after a wait timed out (1 + the peer that never arrived)
-    bool ctr_fine = false;
+    bool ctr_fine = false, data_fine = false;
     TpPeers peers{};
     void* opened[4][TP_MAX] = {};
     hipStream_t sc = nullptr;  // exchange stream
@@ -85,11 +85,14 @@ struct TpComm {
 namespace {
 
 // ---- hand-off ------------------------------------------------------------------------------------------------------
+// `seq` (private) and `ctr` (published) live in one fine-grained block and are only ever touched with system-scope atomics:
+// the 1-thread kernels below land on a different XCD every time, and a plain load could be served from that XCD's L2
+// (a line left there by an earlier owner of the address) instead of memory.
 __global__ void tp_signal_kernel(uint32_t* seq, uint32_t* ctr) {
-    const uint32_t v = *seq + 1u;
-    *seq = v;
-    // the producing kernel retired before this one started (stream order; its end-of-kernel release wrote the XCD L2s
-    // back); this fence + drain orders the counter behind everything this agent has written
+    const uint32_t v = __hip_atomic_load(seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) + 1u;
+    __hip_atomic_store(seq, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // the producing kernel retired before this one started (stream order) and each of its workgroups ended with a
+    // system-scope release; this fence + drain orders the counter behind everything this wave has seen
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __hip_atomic_store(ctr, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -97,13 +100,13 @@ __global__ void tp_signal_kernel(uint32_t* seq, uint32_t* ctr) {
 
 __global__ void tp_wait_kernel(const uint32_t* seq, TpPeers p, int size, int rank, int* err, long long timeout_ticks) {
     const int j = threadIdx.x;
-    if (j < size && j != rank && *err == 0) {
-        const uint32_t v = *seq;
+    if (j < size && j != rank && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0) {
+        const uint32_t v = __hip_atomic_load(seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const long long t0 = wall_clock64();
         while ((int)(__hip_atomic_load(p.ctr[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - v) < 0) {
             __builtin_amdgcn_s_sleep(20);
             if (wall_clock64() - t0 > timeout_ticks) {  // never hang the device: flag it, results are void
-                *err = 1 + j;
+                __hip_atomic_store(err, 1 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 break;
             }
         }
@@ -396,7 +399,8 @@ int tp_forward_body(mmada_handle* h, hipStream_t s) {
     for (int k = 0; k < nch; ++k) sl[k] = chunk_slice(M, tp, c->rank, nch, k);
     const double rows_real = (double)h->B * h->L / M;  // fraction of stream rows that are not padding (FLOP accounting)
     // first RMSNorm of the forward: the embeddings are replicated, no exchange needed
-    if (launch_rmsnorm(h->x, h->layers[0].attn_norm, h->xn, M, d, h->cfg.rms_eps, s)) return 1;
+    if (h->xn_is_layer0) h->xn_is_layer0 = false;  // fused into the embedding kernel
+    else if (launch_rmsnorm(h->x, h->layers[0].attn_norm, h->xn, M, d, h->cfg.rms_eps, s)) return 1;
     bool pending[2] = {false, false};  // chunk k's xn rows are being produced on the exchange stream
     auto after_gemm_exchange = [&](int k, const bf16_t* w) -> int {
         MM_CHECK_HIP(hipEventRecord(c->ev_g[k], s));
@@ -513,7 +517,7 @@ void tp_comm_free(mmada_handle* h) {
         if (c->ev_c[k]) (void)hipEventDestroy(c->ev_c[k]);
     }
     if (c->sc) (void)hipStreamDestroy(c->sc);
-    (void)hipFree(c->part); (void)hipFree(c->hn_pub); (void)hipFree(c->ctr); (void)hipFree(c->seq); (void)hipFree(c->err);
+    (void)hipFree(c->part); (void)hipFree(c->hn_pub); (void)hipFree(c->ctr);
     (void)hipFree(c->rs_tmp); (void)hipFree(c->stats_pub); (void)hipFree(c->stats_all); (void)hipFree(c->head_buf);
     delete c;
     h->tp = nullptr;
@@ -532,24 +536,34 @@ int mmada_comm_create(mmada_handle* h, int max_rows, void* export_out) {
     c->max_rows = max_rows;
     const size_t rows = (size_t)max_rows + 8 * c->size;
     const size_t bytes = rows * c->d * 2;
-    MM_CHECK_HIP(hipMalloc(&c->part, bytes));
-    MM_CHECK_HIP(hipMalloc(&c->hn_pub, bytes));
+    // The hand-off counters and the 16-byte text records are read by other agents while their owner keeps writing them:
+    // fine-grained (coherent) device memory when the runtime grants it.  The two bandwidth-critical buffers (partials,
+    // normalised rows) stay ordinary allocations — a GEMM epilogue's 2-byte stores must combine in L2 — and are handed
+    // over by the release / acquire fences of their producers and consumers; MMADA_TP_FINE_DATA=1 makes them fine-grained too.
+    const char* fd_env = getenv("MMADA_TP_FINE_DATA");
+    const bool fine_data_wanted = fd_env && fd_env[0] == '1';
+    auto alloc_pub = [&](void** p, size_t n, bool want_fine, bool* fine) -> hipError_t {
+        if (want_fine && hipExtMallocWithFlags(p, n, hipDeviceMallocFinegrained) == hipSuccess) {
+            if (fine) *fine = true;
+            return hipSuccess;
+        }
+        (void)hipGetLastError();
+        if (fine) *fine = false;
+        return hipMalloc(p, n);
+    };
+    bool fine_data = false;
+    MM_CHECK_HIP(alloc_pub((void**)&c->part, bytes, fine_data_wanted, &fine_data));
+    MM_CHECK_HIP(alloc_pub((void**)&c->hn_pub, bytes, fine_data_wanted, nullptr));
     MM_CHECK_HIP(hipMemset(c->part, 0, bytes));
     MM_CHECK_HIP(hipMemset(c->hn_pub, 0, bytes));
-    // the counter peers poll must not be served from a stale cache line: fine-grained (coherent) device memory
-    if (hipExtMallocWithFlags((void**)&c->ctr, 64, hipDeviceMallocFinegrained) == hipSuccess) {
-        c->ctr_fine = true;
-    } else {
-        (void)hipGetLastError();
-        MM_CHECK_HIP(hipMalloc(&c->ctr, 64));
-    }
-    MM_CHECK_HIP(hipMemset(c->ctr, 0, 64));
-    MM_CHECK_HIP(hipMalloc(&c->seq, 64));
-    MM_CHECK_HIP(hipMemset(c->seq, 0, 64));
-    MM_CHECK_HIP(hipMalloc(&c->err, 64));
-    MM_CHECK_HIP(hipMemset(c->err, 0, 64));
+    // counters: [0] published sequence number, [64] private sequence number, [128] error flag — 4 KiB of their own
+    MM_CHECK_HIP(alloc_pub((void**)&c->ctr, 4096, true, &c->ctr_fine));
+    MM_CHECK_HIP(hipMemset(c->ctr, 0, 4096));
+    c->seq = c->ctr + 64;
+    c->err = (int*)(c->ctr + 128);
+    c->data_fine = fine_data;
     MM_CHECK_HIP(hipMalloc(&c->rs_tmp, ((size_t)(max_rows + c->size - 1) / c->size + 16) * c->d * 2));
-    MM_CHECK_HIP(hipMalloc(&c->stats_pub, (size_t)STAT_ROWS * sizeof(TextStat)));
+    MM_CHECK_HIP(alloc_pub((void**)&c->stats_pub, (size_t)STAT_ROWS * sizeof(TextStat), true, nullptr));
     MM_CHECK_HIP(hipMemset(c->stats_pub, 0, (size_t)STAT_ROWS * sizeof(TextStat)));
     MM_CHECK_HIP(hipMalloc(&c->stats_all, (size_t)c->size * STAT_ROWS * sizeof(TextStat)));
     int lo = 0, hi = 0;
@@ -646,7 +660,7 @@ int mmada_comm_connect_rccl(mmada_handle* h, const void* unique_id128, const cha
 int mmada_comm_status(mmada_handle* h, int* mode_out, int* err_out, int* finegrained_out, void* stream) {
     if (!h) return mm_fail("mmada_comm_status: null handle");
     if (mode_out) *mode_out = h->tp ? h->tp->mode : 0;
-    if (finegrained_out) *finegrained_out = h->tp ? (int)h->tp->ctr_fine : 0;
+    if (finegrained_out) *finegrained_out = h->tp ? ((int)h->tp->ctr_fine | ((int)h->tp->data_fine << 1)) : 0;
     if (err_out) {
         *err_out = 0;
         if (h->tp) {
@@ -675,6 +689,7 @@ void* mmada_comm_part_ptr(mmada_handle* h) { return h && h->tp ? (void*)h->tp->p
 int mmada_comm_exchange(mmada_handle* h, const void* norm_w, void* stream) {
     if (!h || !h->tp || h->M == 0 || !norm_w) return mm_fail("mmada_comm_exchange: need a comm and a resident carve (mmada_embed)");
     const Slice sl = chunk_slice(h->M, h->tp->size, h->tp->rank, 1, 0);
+    h->xn_is_layer0 = false;  // xn is about to be overwritten
     if (h->tp->mode == 1) hipLaunchKernelGGL(tp_flush_kernel, dim3(256), dim3(64), 0, (hipStream_t)stream);
     return exchange(h, sl, (const bf16_t*)norm_w, (hipStream_t)stream);
 }

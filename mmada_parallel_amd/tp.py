@@ -55,3 +55,34 @@ def shard_layer_weights(weights: dict, cfg: dict, rank: int, size: int) -> dict:
         else:
             out[name] = w
     return out
+
+
+# ---- the library's exchange step (csrc/tp_comm.hip) as plain index arithmetic --------------------------------------------
+def chunk_slices(M: int, size: int, n_chunks: int = 2):
+    """Row plan of one exchange over M stream rows: [(m0, m1, slice)] per chunk; inside a chunk rank r owns rows
+    [m0 + r*slice, min(m1, m0 + (r+1)*slice)).  Every chunk but the last is a multiple of 8*size rows, so only the last one
+    is padded (chunk_slice in csrc/tp_comm.hip)."""
+    unit = 8 * size
+    if n_chunks == 2 and M >= 4 * unit:
+        first = (M // 2 + unit - 1) // unit * unit
+        bounds = [(0, min(first, M)), (min(first, M), M)]
+    else:
+        bounds = [(0, M)]
+    out = []
+    for m0, m1 in bounds:
+        rows = m1 - m0
+        sl = max(8, ((rows + size - 1) // size + 7) // 8 * 8)
+        out.append((m0, m1, sl))
+    return out
+
+
+def owned_rows(M: int, rank: int, size: int, n_chunks: int = 2):
+    """Row ranges of the residual stream rank `rank` keeps (and normalises) — one per chunk."""
+    return [(min(m1, m0 + rank * sl), min(m1, m0 + (rank + 1) * sl)) for m0, m1, sl in chunk_slices(M, size, n_chunks)]
+
+
+def vocab_slice(V: int, rank: int, size: int) -> Tuple[int, int]:
+    """Columns of ff_out.weight rank `rank` multiplies in the vocabulary-parallel text head (mmada_text_select_tp)."""
+    w = ((V + size - 1) // size + 7) // 8 * 8
+    v0 = min(V, rank * w)
+    return v0, min(V, v0 + w)

@@ -90,3 +90,97 @@ def test_shard_plan_covers_every_feature_once():
         assert cover["q_proj"][-1][1] == cfg["d_model"] and cover["ff_out"][-1][1] == cfg["mlp_hidden_size"]
     with pytest.raises(ValueError):
         tp.layer_shards(dict(cfg, n_heads=30, d_model=3840), 0, 4)
+
+
+# ---- the library's exchange (reduce-scatter -> residual + RMSNorm on owned rows -> all-gather) over gloo ----------------
+def _exchange_worker(rank, size, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    torch.set_num_threads(2)
+    from oracle import llada_oracle as lo
+
+    g = torch.Generator().manual_seed(7)           # same data on every rank
+    M, d, V = 200, 256, 1000
+    x = torch.randn(M, d, generator=g).to(torch.bfloat16)
+    parts = [torch.randn(M, d, generator=g).to(torch.bfloat16) for _ in range(size)]
+    w = (1 + 0.1 * torch.randn(d, generator=g)).to(torch.bfloat16)
+    # what csrc/tp_comm.hip does, rank-locally: sum the partial slices of MY rows in rank order (fp32), round, add the
+    # residual, normalise, publish; then collect everybody's rows
+    xn = torch.zeros(M, d, dtype=torch.bfloat16)
+    mine = torch.zeros(M, dtype=torch.bool)
+    for (m0, m1, sl), (r0, r1) in zip(tp.chunk_slices(M, size), tp.owned_rows(M, rank, size)):
+        mine[r0:r1] = True
+        pieces = [torch.zeros(r1 - r0, d) for _ in range(size)]
+        # the "pull": every rank hands the owner its partial of the owner's rows (gloo stands in for the mapped buffers)
+        for owner in range(size):
+            o0, o1 = min(m1, m0 + owner * sl), min(m1, m0 + (owner + 1) * sl)
+            buf = [torch.zeros(o1 - o0, d) for _ in range(size)] if rank == owner else None
+            dist.gather(parts[rank][o0:o1].float(), buf, dst=owner)
+            if rank == owner:
+                pieces = buf
+        acc = torch.zeros(r1 - r0, d)
+        for j in range(size):
+            acc = acc + pieces[j]
+        x_new = (x[r0:r1].float() + acc.to(torch.bfloat16).float()).to(torch.bfloat16)
+        xn[r0:r1] = lo.rms_norm(x_new, w, 1e-5)
+    got = [torch.zeros(M, d, dtype=torch.float32) for _ in range(size)]
+    dist.all_gather(got, torch.where(mine[:, None], xn.float(), torch.zeros(M, d)))
+    full = sum(got).to(torch.bfloat16)
+    total = sum(p.float() for p in parts).to(torch.bfloat16)
+    want = lo.rms_norm((x.float() + total.float()).to(torch.bfloat16), w, 1e-5)
+    ok_rows = bool(torch.equal(full, want))
+    cover = torch.zeros(M)
+    dist.all_reduce(cover.add_(mine.float()))
+    # vocabulary-parallel text statistics: {max, first arg-max, sum-exp} of my columns, combined like tp_text_combine_kernel
+    logits = torch.randn(6, V, generator=g).to(torch.bfloat16)
+    logits[2, 700] = logits[2].max()   # an exact tie across two vocabulary slices: the lowest column must win
+    logits[2, 100] = logits[2].max()
+    v0, v1 = tp.vocab_slice(V, rank, size)
+    loc = logits[:, v0:v1].double()
+    rec = torch.stack([loc.max(1).values, (loc.argmax(1) + v0).double(), (loc - loc.max(1, keepdim=True).values).exp().sum(1)], 1)
+    recs = [torch.zeros_like(rec) for _ in range(size)]
+    dist.all_gather(recs, rec)
+    mx = torch.stack([r[:, 0] for r in recs]).max(0).values
+    arg = torch.zeros(6, dtype=torch.long)
+    tot = torch.zeros(6, dtype=torch.double)
+    for j in reversed(range(size)):
+        arg = torch.where(recs[j][:, 0] == mx, recs[j][:, 1].long(), arg)   # lowest rank holding the maximum wins
+    tot = sum(recs[j][:, 2] * (recs[j][:, 0] - mx).exp() for j in range(size))
+    p_ref = torch.softmax(logits.double(), -1)
+    ok_text = bool(torch.equal(arg, logits.float().argmax(-1))) and \
+        bool(((1.0 / tot - p_ref.gather(1, arg[:, None])[:, 0]).abs() / (1.0 / tot)).max() < 1e-12)
+    out[rank] = (ok_rows, bool((cover == 1).all()), ok_text)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("size", [2, 3])
+def test_exchange_plan_over_gloo(size):
+    """reduce-scatter -> residual add + RMSNorm on the owner's rows -> all-gather, and the vocabulary-parallel text
+    statistics, with world_size gloo processes standing in for the mapped peer buffers: every row is owned exactly once
+    and the result equals the one-process computation bit for bit."""
+    port = 29741 + os.getpid() % 200 + size
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_exchange_worker, args=(size, port, out), nprocs=size, join=True)
+    assert len(out) == size
+    for r in range(size):
+        assert out[r] == (True, True, True), f"rank {r}: {out[r]}"
+
+
+def test_chunk_slices_cover_rows_once_and_match_padding_rules():
+    for size in (2, 4, 8):
+        for M in (8, 72, 216, 2440, 4880, 19520, 39040):
+            for nch in (1, 2):
+                seen = torch.zeros(M, dtype=torch.int32)
+                plan = tp.chunk_slices(M, size, nch)
+                for k, (m0, m1, sl) in enumerate(plan):
+                    assert sl % 8 == 0 and size * sl >= m1 - m0 and size * sl <= (m1 - m0) + 8 * size
+                    if k < len(plan) - 1:
+                        assert (m1 - m0) == size * sl   # only the last chunk is padded
+                for r in range(size):
+                    for r0, r1 in tp.owned_rows(M, r, size, nch):
+                        seen[r0:r1] += 1
+                assert bool((seen == 1).all()), (size, M, nch)
+    assert tp.vocab_slice(134656, 7, 8) == (117824, 134656) and tp.vocab_slice(134656, 0, 8) == (0, 16832)
