@@ -25,6 +25,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the tensor-parallel exchange stream parks a (one-wave) wait kernel until the peers arrive: it must own a hardware queue,
+# not share one with the compute stream (the HIP runtime multiplexes streams over 4 queues by default)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 

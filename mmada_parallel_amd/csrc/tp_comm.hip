@@ -140,6 +140,9 @@ struct ReduceArgs {
 // (the reference: x + attn_out(att) / x + ff_out(h), model/modeling_llada.py:953, 968-970 — every nn.Linear output is
 // rounded to bf16 before the residual add) ; hn = RMSLayerNorm(x[m]) (:315-329, cast-then-scale, same summation order as
 // rmsnorm_row in elementwise.hip, so a row normalises to the same bits on any rank count).
+// TP = compile-time rank count (0: run-time a.size): with it the peer loop unrolls and the tp-1 remote loads of a chunk are
+// all in flight together — one fabric round trip per 16-byte chunk instead of one per (chunk, peer).
+template <int TP>
 __global__ __launch_bounds__(256) void tp_reduce_norm_kernel(ReduceArgs a) {
     const int m = a.r0 + blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= a.r1) return;
@@ -165,13 +168,27 @@ __global__ __launch_bounds__(256) void tp_reduce_norm_kernel(ReduceArgs a) {
                 acc[2 * e + 1] = __uint_as_float(v[e] & 0xffff0000u);
             }
         } else {
-            for (int j = 0; j < a.size; ++j) {
-                const u32x4 v = (j == a.rank) ? ((const u32x4*)(a.part + (size_t)m * a.d))[c]
-                                              : load_sys16(a.p.part[j] + (size_t)m * a.d + c * 8);
+            if constexpr (TP > 0) {
+                u32x4 pv[TP];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    acc[2 * e] += __uint_as_float(v[e] << 16);
-                    acc[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u);
+                for (int j = 0; j < TP; ++j)  // p.part[rank] is this rank's own buffer: one uniform load form, no branch
+                    pv[j] = load_sys16(a.p.part[j] + (size_t)m * a.d + c * 8);
+#pragma unroll
+                for (int j = 0; j < TP; ++j)  // rank order: the sum is the same on whichever rank owns the row
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[2 * e] += __uint_as_float(pv[j][e] << 16);
+                        acc[2 * e + 1] += __uint_as_float(pv[j][e] & 0xffff0000u);
+                    }
+            } else {
+                for (int j = 0; j < a.size; ++j) {
+                    const u32x4 v = (j == a.rank) ? ((const u32x4*)(a.part + (size_t)m * a.d))[c]
+                                                  : load_sys16(a.p.part[j] + (size_t)m * a.d + c * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[2 * e] += __uint_as_float(v[e] << 16);
+                        acc[2 * e + 1] += __uint_as_float(v[e] & 0xffff0000u);
+                    }
                 }
             }
         }
@@ -221,6 +238,7 @@ __global__ __launch_bounds__(256) void tp_gather_kernel(TpPeers p, int rank, int
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // see tp_reduce_norm_kernel
     const bf16_t* src = (use_part ? p.part[owner] : p.hn[owner]) + (size_t)m * d;
     const int nchunk = d >> 3;
+#pragma unroll 8
     for (int c = threadIdx.x & 63; c < nchunk; c += 64) ((u32x4*)(dst + (size_t)m * d))[c] = load_sys16(src + c * 8);
 }
 
@@ -334,7 +352,15 @@ int exchange(mmada_handle* h, const Slice& sl, const bf16_t* norm_w, hipStream_t
     if (c->mode == 1) {
         if (signal_wait(c, s)) return 1;  // every rank's partial of this chunk is complete
         a.nsrc = c->size;
-        if (own > 0) hipLaunchKernelGGL(tp_reduce_norm_kernel, dim3((own + 3) / 4), dim3(256), 0, s, a);
+        if (own > 0) {
+            const dim3 grid((own + 3) / 4), blk(256);
+            switch (c->size) {
+                case 2: hipLaunchKernelGGL(tp_reduce_norm_kernel<2>, grid, blk, 0, s, a); break;
+                case 4: hipLaunchKernelGGL(tp_reduce_norm_kernel<4>, grid, blk, 0, s, a); break;
+                case 8: hipLaunchKernelGGL(tp_reduce_norm_kernel<8>, grid, blk, 0, s, a); break;
+                default: hipLaunchKernelGGL(tp_reduce_norm_kernel<0>, grid, blk, 0, s, a);
+            }
+        }
         if (signal_wait(c, s)) return 1;  // every owner's normalised rows are published
         hipLaunchKernelGGL(tp_gather_kernel, dim3((sl.m1 - sl.m0 + 3) / 4), dim3(256), 0, s, c->peers, c->rank, sl.m0, sl.m1,
                            sl.slice, d, h->xn, 0);
@@ -346,7 +372,7 @@ int exchange(mmada_handle* h, const Slice& sl, const bf16_t* norm_w, hipStream_t
         ncclResult_t r = c->nccl.ReduceScatter(c->part + (size_t)sl.m0 * d, c->rs_tmp, cnt, ncclBfloat16, ncclSum, c->comm, s);
         if (r != ncclSuccess) return nccl_fail(c, "ncclReduceScatter", r);
         a.nsrc = 1; a.presum = c->rs_tmp;
-        if (own > 0) hipLaunchKernelGGL(tp_reduce_norm_kernel, dim3((own + 3) / 4), dim3(256), 0, s, a);
+        if (own > 0) hipLaunchKernelGGL(tp_reduce_norm_kernel<0>, dim3((own + 3) / 4), dim3(256), 0, s, a);
         MM_CHECK_HIP(hipGetLastError());
         // every rank contributes its `slice` rows (rows past M are pad rows of the buffers: never read by a GEMM)
         r = c->nccl.AllGather(c->hn_pub + (size_t)(sl.m0 + c->rank * sl.slice) * d, h->xn + (size_t)sl.m0 * d, cnt,

@@ -22,8 +22,8 @@ def main(path):
     print("kernel,calls,total_ms,avg_us,min_us,max_us,percent")
     for name, n, t, a, lo, hi in rows:
         print(f"\"{short(name)}\",{n},{t/1e6:.3f},{a/1e3:.2f},{lo/1e3:.2f},{hi/1e3:.2f},{100*t/tot:.2f}")
-    # the dominant GEMM split by grid size (M = 2438 vs the batched M = 4876 launches)
-    rows = con.execute("select name, grid_x, count(*), avg(end-start) from kernels where name like '%gemm_bt_128%' "
+    # the GEMMs split by grid size (M = 2438 launches vs the batched M = 4876 launches)
+    rows = con.execute("select name, grid_x, count(*), avg(end-start) from kernels where name like '%gemm_bt_kernel%' "
                        "group by name, grid_x order by name, grid_x").fetchall()
     print("\nkernel,grid_x,calls,avg_us")
     for name, gx, n, a in rows:
