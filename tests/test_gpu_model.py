@@ -532,6 +532,18 @@ def test_generate_image_real_tiny_model_runs_and_is_deterministic(tiny_model):
     assert int(a.min()) >= synth.TEXT_VOCAB and int(a.max()) < synth.TEXT_VOCAB + synth.CODEBOOK  # every slot was filled
     with pytest.raises(TypeError):
         generate_image(object(), job["prompt"], **kw)
+    # use_cache=True: the reference switches its dLLM cache bookkeeping on (model.caching / empty_cache,
+    # generators/image_generation_generator.py:65-68,105-108) but never hands the model a compute mask (:128,141), so the
+    # arithmetic is unchanged — same tokens here, and the model class has the methods the reference's own loop calls
+    c = generate_image(tiny_model, job["prompt"], use_cache=True, **kw)
+    assert torch.equal(a, c)
+    tiny_model.caching(True)
+    ids = job["prompt"].to(DEV)
+    l0 = tiny_model(ids, infer=True, use_cache=False).logits
+    l1 = tiny_model(ids, infer=True, use_cache=True).logits
+    tiny_model.empty_cache()
+    tiny_model.caching(False)
+    assert torch.equal(l0, l1)
 
 
 # ------------------------------------------------------------------------------- mmu_generate (M block-wise text sampler)
