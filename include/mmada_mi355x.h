@@ -295,6 +295,8 @@ int mmada_comm_connect_local(mmada_handle* h, mmada_handle* const* ranks);
 int mmada_comm_unique_id(void* out128, const char* librccl_path);
 int mmada_comm_connect_rccl(mmada_handle* h, const void* unique_id128, const char* librccl_path);
 int mmada_comm_set_mode(mmada_handle* h, int mode);
+/* Hand-off timeout of the pull transport in seconds (<= 0: MMADA_TP_TIMEOUT_S or 20 s); clears a sticky error. */
+int mmada_comm_set_timeout(mmada_handle* h, double seconds);
 int mmada_comm_status(mmada_handle* h, int* mode_out, int* err_out, int* finegrained_out, void* stream);
 void* mmada_comm_part_ptr(mmada_handle* h);
 int mmada_comm_exchange(mmada_handle* h, const void* norm_w, void* stream);

@@ -76,6 +76,7 @@ struct TpComm {
     hipStream_t sc = nullptr;  // exchange stream
     hipEvent_t ev_g[2] = {}, ev_c[2] = {};
     int chunks = 2;
+    long long timeout = 0;     // hand-off timeout in wall_clock64 ticks (100 MHz)
     // RCCL
     RcclApi nccl;
     ncclComm_t comm = nullptr;
@@ -304,18 +305,15 @@ __global__ void tp_flush_kernel() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-long long timeout_ticks() {
-    static const long long t = [] {
-        const char* e = getenv("MMADA_TP_TIMEOUT_S");
-        const double sec = e ? atof(e) : 20.0;
-        return (long long)(sec * 100e6);  // wall_clock64 runs at 100 MHz on gfx9
-    }();
-    return t;
+long long default_timeout_ticks() {
+    const char* e = getenv("MMADA_TP_TIMEOUT_S");
+    const double sec = e ? atof(e) : 20.0;
+    return (long long)(sec * 100e6);  // wall_clock64 runs at 100 MHz on gfx9
 }
 
 int signal_wait(TpComm* c, hipStream_t s) {
     hipLaunchKernelGGL(tp_signal_kernel, dim3(1), dim3(1), 0, s, c->seq, c->ctr);
-    hipLaunchKernelGGL(tp_wait_kernel, dim3(1), dim3(64), 0, s, c->seq, c->peers, c->size, c->rank, c->err, timeout_ticks());
+    hipLaunchKernelGGL(tp_wait_kernel, dim3(1), dim3(64), 0, s, c->seq, c->peers, c->size, c->rank, c->err, c->timeout);
     MM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -601,6 +599,7 @@ int mmada_comm_create(mmada_handle* h, int max_rows, void* export_out) {
     }
     const char* e = getenv("MMADA_TP_CHUNKS");
     c->chunks = e ? atoi(e) : 2;
+    c->timeout = default_timeout_ticks();
     MM_CHECK_HIP(hipDeviceSynchronize());
     h->tp = c;
     if (export_out) {
@@ -679,6 +678,17 @@ int mmada_comm_connect_rccl(mmada_handle* h, const void* unique_id128, const cha
     ncclResult_t r = c->nccl.CommInitRank(&c->comm, c->size, id, c->rank);
     if (r != ncclSuccess) return nccl_fail(c, "ncclCommInitRank", r);
     c->mode = 2;
+    MM_CHECK_HIP(hipMemset(c->err, 0, sizeof(int)));  // a failed attempt with the pull transport must not stick to this one
+    return 0;
+}
+
+/* Hand-off timeout of the pull transport in seconds (<= 0: back to MMADA_TP_TIMEOUT_S / 20 s); also clears a sticky error.
+ * A start-up self-test uses a short one so that a transport that cannot work is abandoned quickly. */
+int mmada_comm_set_timeout(mmada_handle* h, double seconds) {
+    if (!h || !h->tp) return mm_fail("mmada_comm_set_timeout: no comm");
+    h->tp->timeout = seconds > 0 ? (long long)(seconds * 100e6) : default_timeout_ticks();
+    MM_CHECK_HIP(hipDeviceSynchronize());
+    MM_CHECK_HIP(hipMemset(h->tp->err, 0, sizeof(int)));
     return 0;
 }
 
@@ -700,10 +710,12 @@ int mmada_comm_status(mmada_handle* h, int* mode_out, int* err_out, int* finegra
 
 int mmada_comm_set_mode(mmada_handle* h, int mode) {
     if (!h || !h->tp) return mm_fail("mmada_comm_set_mode: no comm");
-    if (mode == 1 && !h->tp->peers.ctr[h->tp->size - 1 == h->tp->rank ? 0 : h->tp->size - 1])
-        return mm_fail("mmada_comm_set_mode: pull transport was never connected");
-    if (mode == 2 && !h->tp->comm) return mm_fail("mmada_comm_set_mode: RCCL transport was never connected");
-    h->tp->mode = mode;
+    TpComm* c = h->tp;
+    const int other = c->rank == 0 ? 1 : 0;
+    if (mode == 1 && !c->peers.ctr[other]) return mm_fail("mmada_comm_set_mode: the pull transport was never connected");
+    if (mode == 2 && !c->comm) return mm_fail("mmada_comm_set_mode: the RCCL transport was never connected");
+    if (mode != 1 && mode != 2) return mm_fail("mmada_comm_set_mode: mode must be 1 (pull) or 2 (RCCL)");
+    c->mode = mode;
     return 0;
 }
 

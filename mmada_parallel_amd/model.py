@@ -439,7 +439,9 @@ class LLaDAForMultiModalGeneration:
             ok = all_agree(ok)
             if ok:
                 self._comm_in_library = True
+                lib.mmada_comm_set_timeout(self._handle, 3.0)   # a transport that cannot work is abandoned quickly
                 ok = all_agree(self.comm_selftest())
+                lib.mmada_comm_set_timeout(self._handle, 0.0)   # back to MMADA_TP_TIMEOUT_S; clears a sticky error
             if ok:
                 chosen = "pull"
             elif transport == "pull":
