@@ -467,6 +467,19 @@ class LLaDAForMultiModalGeneration:
             self._comm_in_library = False
             lib.mmada_comm_destroy(self._handle)
             chosen = "host all-reduce (torch.distributed)"
+        self._rccl_also = False
+        if chosen == "pull" and os.environ.get("MMADA_TP_PROBE_RCCL", "1") == "1":
+            # one rank per device over RCCL as well: connect it too, so collective_probe() can time BOTH transports
+            if all_agree(dist.get_backend(group) == "nccl"):
+                path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()
+                uid = C.create_string_buffer(128)
+                if self.tp_rank == 0:
+                    lib.mmada_comm_unique_id(uid, path)
+                box = [uid.raw]
+                dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+                ok = lib.mmada_comm_connect_rccl(self._handle, box[0], path) == 0   # leaves mode = RCCL
+                self._rccl_also = all_agree(ok)
+                lib.mmada_comm_set_mode(self._handle, 1)                             # the forward keeps the pull transport
         self.tp_collective = chosen
         return chosen
 
@@ -492,9 +505,24 @@ class LLaDAForMultiModalGeneration:
         ms = (time.perf_counter() - t0) / iters * 1e3
         nbytes = B * ((L + 7) // 8 * 8) * self.config.d_model * 2
         tp = self.tp_size
-        return {"transport": self.tp_collective, "rows": B * L, "bytes": nbytes, "ms": ms,
-                "busbw_GBps": 2.0 * (tp - 1) / tp * nbytes / (ms * 1e-3) / 1e9, "exchanges_per_forward": 2 * self.config.n_layers,
-                "status": self.comm_status()}
+        out = {"transport": self.tp_collective, "rows": B * L, "bytes": nbytes, "ms": ms,
+               "busbw_GBps": 2.0 * (tp - 1) / tp * nbytes / (ms * 1e-3) / 1e9, "exchanges_per_forward": 2 * self.config.n_layers,
+               "status": self.comm_status()}
+        if getattr(self, "_rccl_also", False) and self.tp_collective == "pull":   # the same exchange over RCCL, for comparison
+            abi.check(self._lib.mmada_comm_set_mode(self._handle, 2), "mmada_comm_set_mode")
+            try:
+                for _ in range(3):
+                    abi.check(self._lib.mmada_comm_exchange(self._handle, w.data_ptr(), st), "mmada_comm_exchange")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    abi.check(self._lib.mmada_comm_exchange(self._handle, w.data_ptr(), st), "mmada_comm_exchange")
+                torch.cuda.synchronize()
+                ms2 = (time.perf_counter() - t0) / iters * 1e3
+                out["rccl"] = {"ms": ms2, "busbw_GBps": 2.0 * (tp - 1) / tp * nbytes / (ms2 * 1e-3) / 1e9}
+            finally:
+                abi.check(self._lib.mmada_comm_set_mode(self._handle, 1), "mmada_comm_set_mode")
+        return out
 
     def vocab_parallel_head(self) -> bool:
         """True when the text step can run on vocabulary slices of the LM head (library transport connected)."""
