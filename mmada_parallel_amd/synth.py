@@ -63,6 +63,20 @@ def synthetic_state_dict(cfg: dict, seed: int = 0, device: str = "cpu", dtype=to
     return sd
 
 
+def host_isa() -> str:
+    """Which bf16 GEMM code path this host's CPU gives torch / oneDNN: the reference's CPU forward (and therefore every
+    float fixture recorded from it) is bit-reproducible only within one class.  Fixtures that contain float
+    GEMM outputs are stored once per class: tests/golden/<name>.<host_isa>.npz."""
+    try:
+        flags = next(ln for ln in open("/proc/cpuinfo") if ln.startswith("flags")).split()
+    except (OSError, StopIteration):
+        return "other"
+    for key in ("amx_bf16", "avx512_bf16"):
+        if key in flags:
+            return key
+    return "avx512" if "avx512f" in flags else "other"
+
+
 def add_break_line(sequence: List[int], H: int, W: int, new_number: int = 0) -> List[int]:
     """utils/image_utils.py:149-157."""
     result: List[int] = []

@@ -6,14 +6,16 @@ The reference has no tests / golden vectors of its own, so these
 unmodified reference code on seeded synthetic inputs — are what pins the oracle (tests/test_oracle_golden.py)
 and, through it, the HIP path.  Nothing here is copied from the reference; it is imported via sys.path.
 
-Fixtures
-  forward_tiny.npz   LLaDAForMultiModalGeneration(tiny cfg, synthetic weights, bf16)(ids): hidden states after each
+Fixtures  (forward_tiny / e2e_tiny contain the outputs of CPU bf16 GEMMs, which are bit-reproducible only on CPUs of the
+same ISA class — AMX, AVX512-BF16 and plain AVX-512 hosts take different oneDNN kernels.  They are stored
+once per class, <name>.<synth.host_isa()>.npz; this script writes the file of the host it runs on and leaves the others.)
+  forward_tiny.*.npz LLaDAForMultiModalGeneration(tiny cfg, synthetic weights, bf16)(ids): hidden states after each
                      block, logits slices (image rows x codebook columns, text rows x first 4096 columns, per-row
                      top-8) — model/modeling_xllmx_dimoo.py:41-72 + model/modeling_llada.py:1201-1415
   sampler_traj.npz   generate_ti2ti driven by a STUB model that returns seeded random bf16 logits: the ids the
                      sampler passes to every model call + final outputs — generators/parallel_generator.py:102-368
   sampler_noisy.npz  the same at temperature 1.0 / text_temperature 0.7 with every draw taken from a seeded CPU generator
-  e2e_tiny.npz       generate_ti2ti with the real tiny model at temperature 0: ids at every model call + outputs
+  e2e_tiny.*.npz     generate_ti2ti with the real tiny model at temperature 0: ids at every model call + outputs
   logconf_table.npy  torch.log(p + 1e-10) in bf16 for every non-negative bf16 p (parallel_generator.py:36)
   t2i_traj.npz       generate_image (A text-to-image MaskGIT sampler) driven by the same kind of stub model, with and
                      without CFG, temperature 0 and 1 (seeded CPU generator) — generators/image_generation_generator.py
@@ -83,7 +85,9 @@ def stub_logits(seed: int, call_idx: int, B: int, L: int, V: int) -> torch.Tenso
     return (torch.randn(B, L, V, generator=g) * 2.0).to(torch.bfloat16)
 
 
-def gen_forward():
+def compute_forward() -> dict:
+    """The unmodified reference forward on the tiny model, ON THIS HOST (also called live by tests/test_oracle_golden.py
+    when /root/reference is mounted: the oracle must reproduce it bit for bit whatever CPU this is)."""
     from model.modeling_llada import LLaDAModel  # noqa: F401  (import check)
 
     cfg = synth.CFG_TINY
@@ -102,15 +106,20 @@ def gen_forward():
     pos = [i for i in range(job["image_start"], job["image_start"] + job["seq_len"] + job["seq_len"] // job["newline_every"])
            if int(ids[0, i]) != synth.NEW_LINE]
     top = torch.topk(logits[0].float(), 8, dim=-1)
-    np.savez_compressed(
-        os.path.join(OUT, "forward_tiny.npz"),
+    return dict(
         ids=ids.numpy(), hidden=np.stack([bits(t[0]) for t in taps]),
         img_logits=bits(logits[0, pos, synth.TEXT_VOCAB:synth.TEXT_VOCAB + synth.CODEBOOK]),
         text_logits_head=bits(logits[0, ts:te, :4096]),
         top8_val=bits(top.values.to(torch.bfloat16)), top8_idx=top.indices.numpy().astype(np.int32),
         argmax=logits[0].argmax(-1).numpy().astype(np.int32), pos=np.array(pos, np.int32),
     )
-    print("forward_tiny: L =", ids.shape[1], "hidden", taps[0].shape, "logits", tuple(logits.shape))
+
+
+def gen_forward():
+    # float GEMM outputs: one file per host ISA class (synth.host_isa), see the module docstring
+    d = compute_forward()
+    np.savez_compressed(os.path.join(OUT, f"forward_tiny.{synth.host_isa()}.npz"), **d)
+    print(f"forward_tiny.{synth.host_isa()}: L =", d["ids"].shape[1], "hidden", d["hidden"].shape)
 
 
 _SD = None
@@ -192,7 +201,7 @@ def gen_sampler_noisy():
     np.savez_compressed(os.path.join(OUT, "sampler_noisy.npz"), **out)
 
 
-def gen_e2e():
+def compute_e2e() -> dict:
     cfg = synth.CFG_TINY
     model = build_reference_model(cfg, synthetic_sd())
     job = tiny_job()
@@ -203,9 +212,13 @@ def gen_e2e():
 
     kw = dict(text_steps=8, timesteps=4, temperature=0.0, text_temperature=0.0, cfg_scale=0.0, cfg_img=4.0)
     calls, vq, text = run_reference_sampler(fn, job, **kw)
-    np.savez_compressed(os.path.join(OUT, "e2e_tiny.npz"), calls=torch.cat(calls, 0).numpy(), vq=np.array(vq, np.int64),
-                        text=np.array(text, np.int64))
-    print(f"e2e_tiny: {len(calls)} model calls; vq[:8]={vq[:8]}")
+    return dict(calls=torch.cat(calls, 0).numpy(), vq=np.array(vq, np.int64), text=np.array(text, np.int64))
+
+
+def gen_e2e():
+    d = compute_e2e()
+    np.savez_compressed(os.path.join(OUT, f"e2e_tiny.{synth.host_isa()}.npz"), **d)
+    print(f"e2e_tiny.{synth.host_isa()}: {d['calls'].shape[0]} model calls; vq[:8]={d['vq'][:8].tolist()}")
 
 
 # ---- M variant: MMadaModelLM.interleave_generate driven by stub logits and per-call seeded RNG draws ------------------

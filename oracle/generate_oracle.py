@@ -3,7 +3,7 @@
 
 `model_fn(ids) -> logits [B, L, V] bf16` stands for `model(ids, infer=True, use_cache=False).logits` (:178,263,264).
 Every model call's input ids are appended to `trace` so tests can compare trajectories call by call against the
-fixtures recorded from the reference (tests/golden/sampler_traj.npz, e2e_tiny.npz).
+fixtures recorded from the reference (tests/golden/sampler_traj.npz, e2e_tiny.<host class>.npz).
 B == 1 only, like the reference's image branch (:166,224,340).
 """
 from __future__ import annotations

@@ -39,6 +39,18 @@ def bits(t):
     return t.detach().to("cpu", torch.bfloat16).contiguous().view(torch.int16)
 
 
+def golden_float(name, prefer=None):
+    """Float-GEMM fixtures are recorded once per host ISA class (oracle/gen_golden.py): returns (npz, same_class) where
+    same_class says that the file was recorded on a CPU of THIS host's class, i.e. bit-equality with a CPU recomputation
+    may be demanded.  `prefer` picks a particular recording (the GPU tests' thresholds are calibrated on one)."""
+    isa = synth.host_isa()
+    for cand in ([prefer] if prefer else []) + [isa, "amx_bf16", "avx512", "avx512_bf16"]:
+        path = os.path.join(GOLDEN, f"{name}.{cand}.npz")
+        if os.path.exists(path):
+            return np.load(path), cand == isa
+    raise FileNotFoundError(f"no recording of {name} under {GOLDEN}")
+
+
 _SD = {}
 
 

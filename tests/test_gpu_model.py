@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import GOLDEN, ROOT, SAMPLER_CASES, STUB_CB, STUB_TEXT_VOCAB, bits, from_bits, stub_logits, tiny_job, tiny_sd
+from helpers import GOLDEN, ROOT, SAMPLER_CASES, STUB_CB, STUB_TEXT_VOCAB, bits, from_bits, golden_float, stub_logits, tiny_job, tiny_sd
 from mmada_parallel_amd import synth
 
 pytestmark = pytest.mark.gpu
@@ -107,7 +107,7 @@ def test_block_stages_vs_oracle(tiny_model, B):
 def test_forward_hidden_and_logits_vs_oracle_and_reference(tiny_model):
     from oracle import llada_oracle
 
-    z = np.load(os.path.join(GOLDEN, "forward_tiny.npz"))
+    z, _ = golden_float("forward_tiny", prefer="amx_bf16")
     ids = torch.from_numpy(z["ids"])
     tiny_model.forward_body(ids.to(DEV))
     hid = tiny_model.hidden_state().cpu().float()[0]
@@ -246,7 +246,7 @@ def test_teacher_forced_tiny_trajectory(tiny_model):
     from oracle import llada_oracle
     from oracle import sampler_oracle as so
 
-    z = np.load(os.path.join(GOLDEN, "e2e_tiny.npz"))
+    z, _ = golden_float("e2e_tiny", prefer="amx_bf16")
     calls = torch.from_numpy(z["calls"])          # per step: cond, then (uncond_text, uncond_img) on image steps
     job = tiny_job()
     ts, te = job["text_start"], job["text_end"]

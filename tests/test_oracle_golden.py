@@ -6,7 +6,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from helpers import GOLDEN, SAMPLER_CASES, STUB_CB, STUB_TEXT_VOCAB, bits, from_bits, stub_logits, tiny_job, tiny_sd
+from helpers import (GOLDEN, SAMPLER_CASES, STUB_CB, STUB_TEXT_VOCAB, bits, from_bits, golden_float, stub_logits, tiny_job,
+                     tiny_sd)
 from mmada_parallel_amd import synth
 from oracle import generate_oracle, llada_oracle
 from oracle import sampler_oracle as so
@@ -57,33 +58,88 @@ def test_sampler_trajectory_matches_reference(name):
     assert text == z[name + "_text"].tolist()
 
 
-def test_forward_matches_reference():
-    z = np.load(os.path.join(GOLDEN, "forward_tiny.npz"))
+def _live_reference():
+    """oracle/gen_golden.py's compute_* functions run the UNMODIFIED reference on this host; None where the reference tree
+    is not mounted (GPU box)."""
+    if not os.path.isdir("/root/reference/MMaDA-Parallel-A"):
+        return None
+    from oracle import gen_golden
+
+    return gen_golden
+
+
+def _check_forward(z, exact):
     ids = torch.from_numpy(z["ids"])
     sd, cfg = tiny_sd(), synth.CFG_TINY
     taps = []
     x = llada_oracle.forward_hidden(sd, cfg, ids, taps)
     hidden_ref = from_bits(z["hidden"])
-    for i, t in enumerate(taps):
-        assert torch.equal(bits(t[0]), bits(hidden_ref[i])), f"block {i}"
     pos = z["pos"].tolist()
     img = llada_oracle.head(sd, cfg, x[:, pos], synth.TEXT_VOCAB, synth.TEXT_VOCAB + synth.CODEBOOK)
-    assert torch.equal(bits(img[0]), torch.from_numpy(z["img_logits"]))
     job = tiny_job()
     full = llada_oracle.head(sd, cfg, x)
-    assert torch.equal(full[0].argmax(-1).int(), torch.from_numpy(z["argmax"]))
-    assert torch.equal(bits(full[0, job["text_start"]:job["text_end"], :4096]), torch.from_numpy(z["text_logits_head"]))
+    if exact:
+        for i, t in enumerate(taps):
+            assert torch.equal(bits(t[0]), bits(hidden_ref[i])), f"block {i}"
+        # the reference multiplies ALL rows by the whole head matrix (modeling_llada.py:1399-1404); the row / column subset
+        # form `head(x[:, pos], lo, hi)` is the same dot products in a GEMM of another shape, whose blocking (and last bit)
+        # depends on the CPU class: bit-equal on AMX hosts, 1 ulp apart on some entries elsewhere
+        assert torch.equal(bits(full[0, pos, synth.TEXT_VOCAB:synth.TEXT_VOCAB + synth.CODEBOOK]),
+                           torch.from_numpy(z["img_logits"]))
+        ref_img = from_bits(z["img_logits"]).float()
+        assert (img[0].float() - ref_img).abs().max() <= 2.0 ** -7 * ref_img.abs().max()
+        assert torch.equal(full[0].argmax(-1).int(), torch.from_numpy(z["argmax"]))
+        assert torch.equal(bits(full[0, job["text_start"]:job["text_end"], :4096]), torch.from_numpy(z["text_logits_head"]))
+        return
+    # a recording from another CPU class: same arithmetic, another fp32 accumulation order inside the bf16 GEMMs
+    for i, t in enumerate(taps):
+        r = hidden_ref[i].float()
+        err = (t[0].float() - r).abs()
+        assert err.max() <= 2.0 ** -6 * r.abs().max() and err.mean() <= 2.0 ** -9 * r.abs().max(), f"block {i}"
+    ref_img = from_bits(z["img_logits"]).float()
+    assert (img[0].float() - ref_img).abs().mean() <= 2.0 ** -7 * ref_img.abs().max()
+    assert (full[0].argmax(-1).int() == torch.from_numpy(z["argmax"])).float().mean() >= 0.9
 
 
-def test_e2e_tiny_matches_reference():
-    z = np.load(os.path.join(GOLDEN, "e2e_tiny.npz"))
+def test_forward_matches_reference():
+    """(i) /root/reference mounted: the unmodified reference is run HERE and the oracle must equal it bit for bit — the pin,
+    independent of which CPU this is; (ii) the committed recording of this host's ISA class: bit for bit; (iii) recordings
+    of other classes: bf16 re-association tolerance."""
+    live = _live_reference()
+    if live is not None:
+        _check_forward(live.compute_forward(), exact=True)
+    z, same = golden_float("forward_tiny")
+    _check_forward(z, exact=same)
+    if same:  # the other classes' recordings, by tolerance
+        for other in ("amx_bf16", "avx512"):
+            p = os.path.join(GOLDEN, f"forward_tiny.{other}.npz")
+            if other != synth.host_isa() and os.path.exists(p):
+                _check_forward(np.load(p), exact=False)
+
+
+def _oracle_e2e_calls():
     sd, cfg, job = tiny_sd(), synth.CFG_TINY, tiny_job()
     trace = []
     generate_oracle.generate(lambda ids: llada_oracle.forward_logits(sd, cfg, ids), job["input_ids"], job["text_start"],
                              job["text_end"], job["image_start"], job["seq_len"], job["newline_every"], text_steps=8,
                              timesteps=4, cfg_scale=0.0, cfg_img=4.0, uncon_text=job["uncon_text"],
                              uncon_image=job["uncon_image"], trace=trace)
-    assert torch.equal(torch.cat(trace, 0), torch.from_numpy(z["calls"]))
+    return torch.cat(trace, 0)
+
+
+def test_e2e_tiny_matches_reference():
+    got = _oracle_e2e_calls()
+    live = _live_reference()
+    if live is not None:
+        assert torch.equal(got, torch.from_numpy(live.compute_e2e()["calls"]))
+    z, same = golden_float("e2e_tiny")
+    ref = torch.from_numpy(z["calls"])
+    assert got.shape == ref.shape
+    if same:
+        assert torch.equal(got, ref)
+    else:  # free-running on random weights across CPU classes: near-tie flips compound (SURVEY A.10); the first call is the
+        # shared input, and most ids still agree
+        assert torch.equal(got[0], ref[0]) and (got == ref).float().mean() >= 0.6
 
 
 def test_image_probs_against_torch_ops():
