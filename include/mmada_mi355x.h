@@ -116,6 +116,35 @@ int mmada_head_rows(mmada_handle* h, const int32_t* rows, int R, int col_begin, 
  * and mmada_forward refuse to run.  row_begin == row_end clears the window.  The setting persists across forwards. */
 int mmada_set_consumed_rows(mmada_handle* h, int row_begin, int row_end);
 
+/* ---- dLLM cache: LLaDAModel.forward(input_ids, use_cache=True, to_compute_mask=..., cat=...) ---------------------------
+ * (model/modeling_llada.py:1244-1245 token gather, :929-940 per-block k / v cache keyed by `cat`, :714-716,416-428 rotary
+ * positions of the computed queries, :1406-1413 logit cache; caching()/empty_cache() :598-600,1417-1426.)
+ * A slot is one `cat` key: caller-owned device memory that keeps, for B sequences of length L, every block's keys and
+ * values and the residual stream after the last block.  A compute-mask step embeds only the Tc selected tokens of each
+ * sequence, runs every block on those rows — their fresh k / v replace the slot's rows at their positions, their queries
+ * attend to ALL L cached keys — and replaces their rows of the final stream; everything else is reused.  The reference
+ * keeps k / v un-rotated and re-rotates the whole cache every call; the slot keeps them rotated (same values: the rotation
+ * of a row depends on its position only).  The reference also keeps a [B, L, vocab] logit cache; a logit row is a
+ * function of its final-stream row alone, so mmada_cache_head_rows computes any rows on demand instead. */
+
+/* Bytes of one slot for B sequences of length L. */
+size_t mmada_cache_bytes(const mmada_handle* h, int B, int L);
+/* Attach `mem` (256-byte aligned, >= mmada_cache_bytes) as slot `slot` in [0,16) and zero it on `stream` — the reference
+ * creates a cache with torch.zeros_like (:930-932,1407-1408), so never-computed positions have zero keys, values and
+ * logits.  mem == NULL forgets the slot (empty_cache()).  tp_size must be 1. */
+int mmada_cache_bind(mmada_handle* h, int slot, void* mem, size_t bytes, int B, int L, void* stream);
+/* One forward through slot `slot`.  pos == NULL: every token is computed (ids [B,L]); keys / values / final stream of the
+ * whole sequence are stored (the reference's use_cache=True, to_compute_mask=None call).  pos != NULL: ids [B,Tc] are
+ * the tokens at the ascending positions pos [B,Tc] (device int32; the reference's input_ids[to_compute_mask] and
+ * to_compute_mask.nonzero()); q_pos_from_map != 0 rotates the queries by their positions (block.use_cache on, i.e.
+ * caching(True) was called), 0 reproduces the reference's fallback of positions L-Tc..L-1 (:421-425).  Needs the
+ * workspace of (B, L).  Leaves no plain forward resident (mmada_head_rows fails until the next mmada_forward_body). */
+int mmada_forward_cached(mmada_handle* h, int slot, const int64_t* ids, const int32_t* pos, int B, int L, int Tc,
+                         int q_pos_from_map, void* stream);
+/* ln_f + LM head on rows (b*L + l) of the slot's final stream: the rows of logit_cache[cat] (:1409-1413). */
+int mmada_cache_head_rows(mmada_handle* h, int slot, const int32_t* rows, int R, int col_begin, int col_end,
+                          void* logits_out, void* stream);
+
 /* Drop-in full forward: logits_out bf16 device [B, L, vocab] (generators/parallel_generator.py:178,263,264). */
 int mmada_forward(mmada_handle* h, const int64_t* ids, int B, int L, void* logits_out, void* stream);
 

@@ -40,6 +40,10 @@ SIGNATURES = {
     "mmada_set_consumed_rows": (c_int, [c_void_p, c_int, c_int]),
     "mmada_forward_body": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mmada_head_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "mmada_cache_bytes": (c_size_t, [c_void_p, c_int, c_int]),
+    "mmada_cache_bind": (c_int, [c_void_p, c_int, c_void_p, c_size_t, c_int, c_int, c_void_p]),
+    "mmada_forward_cached": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "mmada_cache_head_rows": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mmada_forward": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "mmada_embed": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "mmada_attn_partial": (c_int, [c_void_p, c_int, c_void_p]),

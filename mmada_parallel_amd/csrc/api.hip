@@ -154,6 +154,7 @@ static int apply_carve(mmada_handle* h, int B, int L, hipStream_t s) {
     h->att = (bf16_t*)(h->ws + c.att); h->hbuf = (bf16_t*)(h->ws + c.h); h->q = (bf16_t*)(h->ws + c.q);
     h->k = (bf16_t*)(h->ws + c.k); h->vT = (bf16_t*)(h->ws + c.vT); h->xg = (bf16_t*)(h->ws + c.xg);
     h->rows_all = (int32_t*)(h->ws + c.rows);
+    h->posmap = (int32_t*)(h->ws + c.posmap);
     // vT columns never written by the QKV epilogue (keys >= Lp; the key order inside a 16-key group is permuted, so
     // start at the last group boundary) are multiplied by P == 0: keep them finite
     const int z0 = c.Lp & ~15;
@@ -197,6 +198,11 @@ int mmada_attn_partial(mmada_handle* h, int layer, void* stream) {
     g.lda = d; g.ldw = d; g.ldc = 0;
     g.q = h->q; g.k = h->k; g.vT = h->vT; g.rope_cos = h->rope_cos; g.rope_sin = h->rope_sin;
     g.Lp = h->Lp; g.Lkv = h->Lkv; g.Hq = h->hq_l; g.Hkv = h->hkv_l;
+    const CacheSlot* cc = h->cc;  // dLLM cache step: this block's keys / values live in (and are written to) the slot
+    if (cc) {
+        g.k = cc->K(layer); g.vT = cc->vT(layer); g.Lkv = cc->Lkv;
+        g.pos_map = h->cc_pos; g.Lq = h->Lkv; g.q_pos_shift = h->cc_qshift;
+    }
     const double rows = (double)h->B * h->L;
     {
         ProfScope p(h, layer, 0, 2.0 * rows * g.N * g.K, s);
@@ -205,7 +211,7 @@ int mmada_attn_partial(mmada_handle* h, int layer, void* stream) {
     // last block + consumed-row window: only the rows the caller will read are attended / projected (bit-identical on
     // them: the window start is rounded down to the 32-query wave granule, so every wave sees the queries it saw before)
     int wbeg = 0, W = 0;
-    if (layer == h->cfg.n_layers - 1 && h->win_end > h->win_beg) {
+    if (!cc && layer == h->cfg.n_layers - 1 && h->win_end > h->win_beg) {
         if (h->win_end > h->L) return mm_fail("forward: consumed rows [%d,%d) exceed L=%d", h->win_beg, h->win_end, h->L);
         wbeg = h->win_beg & ~31;
         W = h->win_end - wbeg;
@@ -214,8 +220,11 @@ int mmada_attn_partial(mmada_handle* h, int layer, void* stream) {
     const int Mo = W ? h->B * W : h->M;
     const double orows = W ? (double)h->B * W : rows;
     {
-        ProfScope p(h, layer, 1, 4.0 * h->hq_l * orows * h->L * 128.0, s);
-        if (W) {
+        ProfScope p(h, layer, 1, 4.0 * h->hq_l * orows * (cc ? cc->L : h->L) * 128.0, s);
+        if (cc) {  // compact (or all) queries of this call against the slot's keys / values of the whole sequence
+            if (launch_attention(h->q, g.k, g.vT, h->att, h->B, h->hq_l, h->hkv_l, cc->L, h->Lp, cc->Lkv, h->Lp,
+                                 h->hq_l * 128, s, 0, h->Lkv)) return 1;
+        } else if (W) {
             if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->win_end, h->Lkv, W,
                                  h->hq_l * 128, s, wbeg)) return 1;
         } else if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->Lp, h->Lkv, h->Lp,
@@ -307,6 +316,110 @@ int mmada_forward_body(mmada_handle* h, const int64_t* ids, int B, int L, void* 
         if (mmada_mlp_partial(h, i, stream)) return 1;
     }
     return 0;
+}
+
+// ---- dLLM cache (model/modeling_llada.py:593-600,929-940,1244-1245,1406-1426) -----------------------------------------
+static void slot_layout(const mmada_handle* h, int B, int L, CacheSlot& c) {
+    c.B = B; c.L = L; c.Lp = ceil_to(L, 8); c.Lkv = ceil_to(L, 64);
+    c.kv_bytes = align_up((size_t)B * h->hkv_l * c.Lkv * 128 * 2, 256);
+    c.layer_stride = 2 * c.kv_bytes;
+    c.bytes = (size_t)h->cfg.n_layers * c.layer_stride + align_up((size_t)B * c.Lp * h->cfg.d_model * 2, 256);
+}
+
+size_t mmada_cache_bytes(const mmada_handle* h, int B, int L) {
+    if (!h || B <= 0 || L <= 0) return 0;
+    CacheSlot c;
+    slot_layout(h, B, L, c);
+    return c.bytes;
+}
+
+int mmada_cache_bind(mmada_handle* h, int slot, void* mem, size_t bytes, int B, int L, void* stream) {
+    if (!h) return mm_fail("mmada_cache_bind: null handle");
+    if (slot < 0 || slot >= MMADA_CACHE_SLOTS) return mm_fail("mmada_cache_bind: slot %d outside [0,%d)", slot, MMADA_CACHE_SLOTS);
+    if (!mem) {  // release
+        h->slots[slot] = CacheSlot{};
+        return 0;
+    }
+    if (h->cfg.tp_size != 1) return mm_fail("mmada_cache_bind: the dLLM cache path is single-rank (tp_size=%d)", h->cfg.tp_size);
+    if (B <= 0 || L <= 0 || L > h->cfg.max_seq) return mm_fail("mmada_cache_bind: bad shape B=%d L=%d", B, L);
+    if (((uintptr_t)mem) & 255) return mm_fail("mmada_cache_bind: memory must be 256-byte aligned");
+    CacheSlot c;
+    slot_layout(h, B, L, c);
+    if (bytes < c.bytes) return mm_fail("mmada_cache_bind: %zu bytes given, %zu needed", bytes, c.bytes);
+    c.mem = (char*)mem;
+    // the reference starts a cache at zeros (torch.zeros_like, :930-932,1407-1408): a never-computed position has zero
+    // keys / values (a zero score, a zero value row) and zero logits (ln_f(0) = 0)
+    MM_CHECK_HIP(hipMemsetAsync(mem, 0, c.bytes, (hipStream_t)stream));
+    h->slots[slot] = c;
+    return 0;
+}
+
+int mmada_forward_cached(mmada_handle* h, int slot, const int64_t* ids, const int32_t* pos, int B, int L, int Tc,
+                         int q_pos_from_map, void* stream) {
+    if (!h || !ids) return mm_fail("mmada_forward_cached: null argument");
+    if (slot < 0 || slot >= MMADA_CACHE_SLOTS || !h->slots[slot].mem) return mm_fail("mmada_forward_cached: slot %d is not bound", slot);
+    const CacheSlot& c = h->slots[slot];
+    if (c.B != B || c.L != L) return mm_fail("mmada_forward_cached: slot holds B=%d L=%d, call has B=%d L=%d", c.B, c.L, B, L);
+    if (h->cfg.tp_size != 1) return mm_fail("mmada_forward_cached: single-rank only");
+    if (!pos) Tc = L;
+    if (Tc <= 0 || Tc > L) return mm_fail("mmada_forward_cached: Tc=%d outside (0,%d]", Tc, L);
+    hipStream_t s = (hipStream_t)stream;
+    if (check_bound(h)) return 1;
+    // buffers are carved for the whole (B, L) shape — mmada_cache_head_rows may ask for any row — and the blocks then run on
+    // the compact [B, ceil8(Tc)] stream of the computed tokens
+    if (apply_carve(h, B, L, s)) return 1;
+    if (pos) {
+        h->L = Tc; h->Lp = ceil_to(Tc, 8); h->Lkv = ceil_to(Tc, 64); h->M = B * h->Lp;
+        if (launch_expand_pos(pos, h->posmap, B, Tc, h->Lp, L, s)) return 1;
+    }
+    h->cur_W = 0; h->cur_beg = 0; h->Mcur = h->M;
+    h->xn_is_final = false;
+    h->xn_is_layer0 = true;
+    const int d = h->cfg.d_model;
+    if (launch_embed(ids, h->wte, h->x, B, h->L, h->Lp, d, h->cfg.vocab, s, h->layers[0].attn_norm, h->xn, h->cfg.rms_eps))
+        return 1;
+    h->cc = &c;
+    h->cc_pos = pos ? h->posmap : nullptr;
+    h->cc_qshift = (pos && !q_pos_from_map) ? L - Tc : -1;
+    int rc = 0;
+    for (int i = 0; i < h->cfg.n_layers && !rc; ++i) {
+        rc = mmada_attn_partial(h, i, stream);
+        if (!rc) rc = mmada_mlp_partial(h, i, stream);
+    }
+    h->cc = nullptr; h->cc_pos = nullptr; h->cc_qshift = -1;
+    if (rc) { h->M = 0; return 1; }
+    // the rows just computed replace theirs in the slot's final residual stream (the reference scatters the logits,
+    // :1409-1411; a logit row is a function of its residual row alone, so the head runs on demand: mmada_cache_head_rows)
+    bf16_t* xfin = c.xfin(h->cfg.n_layers);
+    if (pos) {
+        if (launch_scatter_rows(h->x, xfin, h->posmap, h->M, h->Lp, c.Lp, d, s)) return 1;
+    } else {
+        MM_CHECK_HIP(hipMemcpyAsync(xfin, h->x, (size_t)h->M * d * 2, hipMemcpyDeviceToDevice, s));
+    }
+    h->M = 0;  // no plain forward is resident: mmada_head_rows / mmada_read_stream must not read the compact stream
+    return 0;
+}
+
+int mmada_cache_head_rows(mmada_handle* h, int slot, const int32_t* rows, int R, int col_begin, int col_end,
+                          void* logits_out, void* stream) {
+    if (!h || !rows || !logits_out) return mm_fail("mmada_cache_head_rows: null argument");
+    if (slot < 0 || slot >= MMADA_CACHE_SLOTS || !h->slots[slot].mem) return mm_fail("mmada_cache_head_rows: slot %d is not bound", slot);
+    const CacheSlot& c = h->slots[slot];
+    if (R <= 0) return 0;
+    if (R > c.B * c.L) return mm_fail("mmada_cache_head_rows: R=%d exceeds B*L=%d", R, c.B * c.L);
+    if (col_begin < 0 || col_end > h->cfg.vocab || col_begin >= col_end) return mm_fail("mmada_cache_head_rows: bad column range");
+    const Carve cv = carve_for(h, c.B, c.L);
+    if (!h->ws || cv.total > h->ws_bytes) return mm_fail("mmada_cache_head_rows: workspace too small (%zu needed)", cv.total);
+    hipStream_t s = (hipStream_t)stream;
+    const int d = h->cfg.d_model;
+    bf16_t* xg = (bf16_t*)(h->ws + cv.xg);
+    if (launch_rmsnorm_gather(c.xfin(h->cfg.n_layers), h->ln_f, xg, rows, R, c.L, c.Lp, d, h->cfg.rms_eps, s, 0, c.B * c.L))
+        return 1;
+    GemmArgs g{};
+    g.A = xg; g.W = h->lm_head + (size_t)col_begin * d; g.C = (bf16_t*)logits_out;
+    g.M = R; g.N = col_end - col_begin; g.K = d;
+    g.lda = d; g.ldw = d; g.ldc = g.N;
+    return launch_gemm(EPI_STORE, g, s);
 }
 
 int mmada_head_rows(mmada_handle* h, const int32_t* rows, int R, int col_begin, int col_end, void* logits_out,

@@ -152,6 +152,35 @@ __global__ void iota_kernel(int32_t* rows, int n) {
     if (i < n) rows[i] = i;
 }
 
+// ---- dLLM cache helpers (compute-mask forward, model/modeling_llada.py:929-937,1244-1245,1409-1411) ----------------
+// posmap[b*Lp + i] = position of the i-th computed token of sequence b, -1 on the pad rows of the compact stream;
+// a position outside [0, L) also becomes -1 (torch would raise; the device stays safe)
+__global__ void expand_pos_kernel(const int32_t* __restrict__ pos, int32_t* __restrict__ posmap, int B, int Tc, int Lp, int L) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= B * Lp) return;
+    const int b = m / Lp, i = m - b * Lp;
+    int p = -1;
+    if (i < Tc) {
+        p = pos[b * Tc + i];
+        if (p < 0 || p >= L) p = -1;
+    }
+    posmap[m] = p;
+}
+
+// dst[b*Lp_dst + posmap[m]] = src[m] for the mapped rows of the compact stream (one wave per row)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
+                                                           const int32_t* __restrict__ posmap, int M, int Lp, int Lp_dst,
+                                                           int d) {
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int p = posmap[m];
+    if (p < 0) return;
+    const int b = m / Lp;
+    const u32x4* s = (const u32x4*)(src + (size_t)m * d);
+    u32x4* o = (u32x4*)(dst + ((size_t)b * Lp_dst + p) * d);
+    for (int c = threadIdx.x & 63; c < (d >> 3); c += 64) o[c] = s[c];
+}
+
 // ---- weight repack (one wave copies one output row of d bf16) --------------------------------------------------
 // Fused QKV with the rotary-partner permutation: inside each q/k head, packed column c = 32*p + w holds original
 // feature i = 16*p + (w & 15) + (w >= 16 ? 64 : 0), so the two 16-wide MFMA fragments 2p and 2p+1 of a lane are
@@ -286,6 +315,15 @@ int launch_unpad_rows(const bf16_t* x, bf16_t* out, int B, int L, int Lp, int d,
 }
 int launch_iota_rows(int32_t* rows, int n, hipStream_t s) {
     hipLaunchKernelGGL(iota_kernel, dim3((n + 255) / 256), dim3(256), 0, s, rows, n);
+    LAUNCH_CHECK();
+}
+int launch_expand_pos(const int32_t* pos, int32_t* posmap, int B, int Tc, int Lp, int L, hipStream_t s) {
+    hipLaunchKernelGGL(expand_pos_kernel, dim3((B * Lp + 255) / 256), dim3(256), 0, s, pos, posmap, B, Tc, Lp, L);
+    LAUNCH_CHECK();
+}
+int launch_scatter_rows(const bf16_t* src, bf16_t* dst, const int32_t* posmap, int M, int Lp, int Lp_dst, int d,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((M + 3) / 4), dim3(256), 0, s, src, dst, posmap, M, Lp, Lp_dst, d);
     LAUNCH_CHECK();
 }
 int launch_pack_qkv(const bf16_t* wq, const bf16_t* wk, const bf16_t* wv, bf16_t* out, int d, int Hq, int Hkv, int tp_rank,

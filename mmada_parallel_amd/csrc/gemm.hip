@@ -229,8 +229,20 @@ MM_DEVICE void epilogue(const GemmArgs& g, int m0, int n0,
                     const int m = mrow0 + mi * 16 + r;
                     if (m >= g.M) continue;
                     const int mg = m + g.m_base;  // row of the whole [B*Lp] stream
-                    const int b = mg / g.Lp, l = mg - b * g.Lp;
-                    bf16_t* row = dst + ((size_t)(b * nh + hh) * g.Lkv + l) * 128;
+                    const int b = mg / g.Lp;
+                    int l = mg - b * g.Lp;        // rotary position
+                    int lrow = l, lstride = g.Lkv;  // destination row / rows per head
+                    if (g.pos_map) {
+                        const int pos = g.pos_map[mg];
+                        if (isq) {
+                            lrow = l; lstride = g.Lq;
+                            l = g.q_pos_shift >= 0 ? l + g.q_pos_shift : (pos < 0 ? 0 : pos);
+                        } else {
+                            if (pos < 0) continue;  // pad row of the compact stream: never enters the cache
+                            l = lrow = pos;
+                        }
+                    }
+                    bf16_t* row = dst + ((size_t)(b * nh + hh) * lstride + lrow) * 128;
 #pragma unroll
                     for (int q2 = 0; q2 < FN / 2; ++q2) {
                         // permuted column layout: fragments (2*q2, 2*q2+1) hold rotary partners i and i+64
@@ -252,6 +264,21 @@ MM_DEVICE void epilogue(const GemmArgs& g, int m0, int n0,
                 if (mb >= g.M) continue;
                 const int mbg = mb + g.m_base;  // m_base is a multiple of 8: the 4 rows still share a batch element
                 const int b = mbg / g.Lp, l0 = mbg - b * g.Lp;
+                if (g.pos_map) {  // scattered rows: one 2-byte store per (row, d); only the computed rows of a cache step
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (mb + r >= g.M) continue;
+                        const int pos = g.pos_map[mbg + r];
+                        if (pos < 0) continue;
+                        const size_t kp = (size_t)vt_key_pos(pos & ~3) + (pos & 3);
+#pragma unroll
+                        for (int ni = 0; ni < FN; ++ni) {
+                            const int d = c0 + ni * 16 + frow;
+                            g.vT[((size_t)(b * g.Hkv + hv) * 128 + d) * g.Lkv + kp] = f2bf(acc[mi][ni][r]);
+                        }
+                    }
+                    continue;
+                }
 #pragma unroll
                 for (int ni = 0; ni < FN; ++ni) {
                     const int d = c0 + ni * 16 + frow;

@@ -18,6 +18,19 @@ struct LayerWeights {
     bool bound = false;
 };
 
+// One dLLM-cache slot (the reference's `cat` key: model/modeling_llada.py:593-597,929-940,1406-1413): caller-owned device
+// memory holding, for B sequences of length L, every block's keys (rotated, attention layout) and K-major values plus
+// the residual stream after the last block; see mmada_cache_bind.
+struct CacheSlot {
+    char* mem = nullptr;
+    size_t bytes = 0, layer_stride = 0, kv_bytes = 0;
+    int B = 0, L = 0, Lp = 0, Lkv = 0;
+    bf16_t* K(int layer) const { return (bf16_t*)(mem + (size_t)layer * layer_stride); }
+    bf16_t* vT(int layer) const { return (bf16_t*)(mem + (size_t)layer * layer_stride + kv_bytes); }
+    bf16_t* xfin(int n_layers) const { return (bf16_t*)(mem + (size_t)n_layers * layer_stride); }
+};
+constexpr int MMADA_CACHE_SLOTS = 16;
+
 struct mmada_handle {
     mmada_cfg cfg;
     int hq_l, hkv_l, f_l;  // per-rank heads / mlp columns
@@ -36,6 +49,13 @@ struct mmada_handle {
     bf16_t *x = nullptr, *y = nullptr, *xn = nullptr, *att = nullptr, *hbuf = nullptr, *q = nullptr, *k = nullptr,
            *vT = nullptr, *xg = nullptr;
     int32_t* rows_all = nullptr;
+    int32_t* posmap = nullptr;  // [B*Lp] sequence position of every compact stream row (compute-mask forward)
+    // dLLM cache: slots, and the one a forward in flight writes its keys / values into (cc != null only inside
+    // mmada_forward_cached); cc_pos: position map of a compute-mask step (null: every row is computed)
+    CacheSlot slots[MMADA_CACHE_SLOTS];
+    const CacheSlot* cc = nullptr;
+    const int32_t* cc_pos = nullptr;
+    int cc_qshift = -1;
     // consumed-row window (mmada_set_consumed_rows): requested [win_beg, win_end) per sequence; while a forward whose
     // last block ran windowed is resident, the stream is compact: cur_W rows per sequence starting at row cur_beg
     int win_beg = 0, win_end = 0;
@@ -87,7 +107,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static inline int ceil_to(int v, int a) { return (v + a - 1) / a * a; }
 
 struct Carve {
-    size_t x, y, xn, att, h, q, k, vT, xg, rows, total;
+    size_t x, y, xn, att, h, q, k, vT, xg, rows, posmap, total;
     int Lp, Lkv, M;
 };
 
@@ -116,6 +136,7 @@ static Carve carve_for(const mmada_handle* h, int B, int L) {
     c.vT = take((size_t)B * h->hkv_l * 128 * c.Lkv * 2);
     c.xg = take((size_t)B * L * d * 2);
     c.rows = take((size_t)B * L * 4);
+    c.posmap = take((size_t)c.M * 4);
     c.total = off;
     return c;
 }

@@ -33,6 +33,13 @@ struct GemmArgs {
     int publish;       // != 0: C is read by OTHER agents / other XCDs' kernels polling a counter (tensor-parallel partials):
                        // every workgroup ends with a system-scope release so its stores have left this XCD's L2
     int m_base;        // EPI_QKV on a row chunk: A/M describe rows [m_base, m_base+M) of the [B*Lp] stream (b, l from m_base+m)
+    // EPI_QKV with a position map (compute-mask forward of the dLLM cache, model/modeling_llada.py:929-937): stream row
+    // m = b*Lp + i is the token at sequence position pos_map[m] (< 0: pad row).  q goes to the COMPACT row i of
+    // q [B, Hq, Lq, 128]; k / v are scattered to row pos of the cache-resident k / vT (stride Lkv); nothing of a pad row is
+    // kept.  Rotary position: k always pos; q pos, or i + q_pos_shift when q_pos_shift >= 0 (the reference's rotary
+    // q_mask quirk with caching() off, :714-716,416-428).
+    const int32_t* pos_map;
+    int Lq, q_pos_shift;
 };
 
 int launch_gemm(int epi, const GemmArgs& g, hipStream_t s);
@@ -49,6 +56,9 @@ int launch_rmsnorm_gather(const bf16_t* x, const bf16_t* w, bf16_t* out, const i
 int launch_rope_table(float* cos_t, float* sin_t, const float* inv_freq_dev, int max_seq, hipStream_t s);
 int launch_unpad_rows(const bf16_t* x, bf16_t* out, int B, int L, int Lp, int d, hipStream_t s);
 int launch_iota_rows(int32_t* rows, int n, hipStream_t s);
+// dLLM cache helpers: posmap[b*Lp + i] = pos[b*Tc + i] (i < Tc) or -1; dst[b*Lp_dst + pos] = src[b*Lp + i] for mapped rows
+int launch_expand_pos(const int32_t* pos, int32_t* posmap, int B, int Tc, int Lp, int L, hipStream_t s);
+int launch_scatter_rows(const bf16_t* src, bf16_t* dst, const int32_t* posmap, int M, int Lp, int Lp_dst, int d, hipStream_t s);
 // weight repack
 int launch_pack_qkv(const bf16_t* wq, const bf16_t* wk, const bf16_t* wv, bf16_t* out, int d, int Hq, int Hkv, int tp_rank,
                     int tp_size, hipStream_t s);
@@ -61,8 +71,10 @@ int launch_transpose_v(const bf16_t* v, bf16_t* vT, int BH, int L, int Lkv, hipS
 int launch_lfq_gather(const int64_t* idx, void* out, int B, int N, int nbits, int f32, hipStream_t s);
 
 // attention.hip:  q [B,Hq,Lkv,128], k [B,Hkv,Lkv,128], vT [B,Hkv,128,Lkv] -> out rows (b*Lp_out + l) x (Hq*128)
+// Lq_alloc > 0: q is [B,Hq,Lq_alloc,128] (compact queries against longer cached keys); 0: q shares the keys' Lkv
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int B, int Hq, int Hkv, int L,
-                     int Lq_rows, int Lkv, int out_row_stride_per_batch, int ld_out, hipStream_t s, int q_begin = 0);
+                     int Lq_rows, int Lkv, int out_row_stride_per_batch, int ld_out, hipStream_t s, int q_begin = 0,
+                     int Lq_alloc = 0);
 
 // sampler.hip
 struct TextStat { float lmax; int32_t arg; double sum; };  // one rank's record of a text row (vocabulary-parallel head)

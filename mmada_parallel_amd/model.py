@@ -340,12 +340,26 @@ class LLaDAForMultiModalGeneration:
             t = t.reshape(B, hkv, 128, lkv.value // 16, 4, 4)[..., [0, 2, 1, 3], :].reshape(B, hkv, 128, lkv.value)
         return t
 
-    def forward(self, input_ids=None, labels=None, infer=False, use_cache=False, **_):
+    def forward(self, input_ids=None, labels=None, infer=False, use_cache=False, to_compute_mask=None, cat="", **_):
+        """LLaDAForMultiModalGeneration.forward(infer=True) (model/modeling_xllmx_dimoo.py:41-72) -> logits [B, L, vocab].
+
+        use_cache / to_compute_mask / cat are LLaDAModelLM.forward's dLLM-cache arguments (model/modeling_llada.py:
+        1468-1493,1244-1245,929-940,1406-1413): with use_cache=True the call goes through the cache slot of `cat`
+        (forward_cached); to_compute_mask [B, L] bool then selects the tokens that are recomputed — every other position's
+        keys, values and logits are reused — and the returned logits are the whole logit cache, as in the reference."""
         if not infer or labels is not None:
             raise NotImplementedError("only forward(infer=True) is on the MI355X hot path (training loss is out of scope)")
-        # use_cache: the reference wrapper forwards only the flag, never a `to_compute_mask`
-        # (model/modeling_xllmx_dimoo.py:41-72), so the blocks merely keep references to this call's k/v and logits
-        # (model/modeling_llada.py:929-940, 1406-1413) — every row is recomputed and the logits are unchanged.
+        if to_compute_mask is not None and not use_cache:
+            raise ValueError("to_compute_mask needs use_cache=True (the reference only gathers the tokens then, "
+                             "model/modeling_llada.py:1244-1245)")
+        if use_cache and self.tp_size == 1:
+            self.forward_cached(input_ids, to_compute_mask=to_compute_mask, cat=cat)
+            B, L = self._cache[cat].shape
+            rows = torch.arange(B * L, dtype=torch.int32, device=self.device)
+            return CausalLMOutputLite(logits=self.cache_head_rows(cat, rows, 0, self.vocab).view(B, L, self.vocab))
+        if to_compute_mask is not None:
+            raise NotImplementedError("the dLLM cache path is single-rank (tp_size == 1)")
+        # tensor parallel + use_cache without a mask: every row is recomputed and nothing is kept (same logits)
         self.forward_body(input_ids)
         B, L = self._shape
         rows = torch.arange(B * L, dtype=torch.int32, device=self.device)
@@ -533,15 +547,86 @@ class LLaDAForMultiModalGeneration:
         capture a whole denoise step into one hipGraph (mmada_graph_*)."""
         return self.tp_size == 1 or getattr(self, "_comm_in_library", False)
 
+    # ---- dLLM cache (model/modeling_llada.py:593-600,929-940,1244-1245,1406-1426) ----------------------------------------
     def caching(self, enable: bool = True):
-        """LLaDAModelLM.caching (model/modeling_llada.py:1417-1421, 1560-1561): switches the dLLM cache bookkeeping on or
-        off and clears it.  Callers of this model never hand it a compute mask, so the switch has no arithmetic effect; it
-        exists so the reference's own `generate_image` (generators/image_generation_generator.py:65-68) runs on this
-        class unmodified."""
+        """LLaDAModel.caching (model/modeling_llada.py:1417-1421 -> every block's :598-600): sets the blocks' use_cache flag
+        — which only decides whether the queries of a compute-mask step are rotated by their own positions (:714-716) — and
+        clears every cache."""
         self.use_cache = bool(enable)
+        self.empty_cache()
 
     def empty_cache(self):
-        """LLaDAModelLM.empty_cache (model/modeling_llada.py:1423-1426, 1563-1564): drops cached k/v/logits (none kept)."""
+        """LLaDAModel.empty_cache (model/modeling_llada.py:1423-1426): drops every slot's keys / values / final rows."""
+        for ent in getattr(self, "_cache", {}).values():
+            abi.check(self._lib.mmada_cache_bind(self._handle, ent.idx, None, 0, 0, 0, abi.stream_ptr()), "mmada_cache_bind")
+        self._cache = {}
+
+    def _cache_slot(self, cat, B: int, L: int, rebind_ok: bool):
+        from types import SimpleNamespace
+
+        cache = self.__dict__.setdefault("_cache", {})
+        ent = cache.get(cat)
+        if ent is not None and ent.shape == (B, L):
+            return ent
+        if ent is not None and not rebind_ok:
+            raise ValueError(f"cache {cat!r} holds sequences of shape {ent.shape}, the masked call has {(B, L)}")
+        if ent is None:
+            used = {e.idx for e in cache.values()}
+            free = [i for i in range(16) if i not in used]
+            if not free:
+                raise abi.MmadaError("all 16 dLLM cache slots are in use (empty_cache() releases them)")
+            idx = free[0]
+        else:
+            idx = ent.idx
+        nbytes = self._lib.mmada_cache_bytes(self._handle, B, L)
+        mem = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        base = (mem.data_ptr() + 255) // 256 * 256
+        abi.check(self._lib.mmada_cache_bind(self._handle, idx, base, nbytes, B, L, abi.stream_ptr()), "mmada_cache_bind")
+        cache[cat] = SimpleNamespace(idx=idx, mem=mem, shape=(B, L))
+        return cache[cat]
+
+    def forward_cached(self, input_ids: torch.Tensor, to_compute_mask: Optional[torch.Tensor] = None, cat="") -> None:
+        """One forward through the cache slot `cat` (created at zeros on first use, like the reference's zeros_like).
+        Mask None: every token is computed and the slot is (re)filled.  Mask [B, L] bool with the same count in every
+        row (the reference's `.view(B, -1)`): only those tokens run through the blocks; read logits with cache_head_rows."""
+        if self.tp_size != 1:
+            raise NotImplementedError("the dLLM cache path is single-rank (tp_size == 1)")
+        ids = input_ids.to(device=self.device, dtype=torch.long).contiguous()
+        B, L = ids.shape
+        self._ensure_ws(B, L)
+        ent = self._cache_slot(cat, B, L, rebind_ok=to_compute_mask is None)
+        st = abi.stream_ptr()
+        if to_compute_mask is None:
+            abi.check(self._lib.mmada_forward_cached(self._handle, ent.idx, ids.data_ptr(), None, B, L, L, 1, st),
+                      "mmada_forward_cached")
+        else:
+            m = to_compute_mask.to(device=self.device, dtype=torch.bool)
+            if m.shape != (B, L):
+                raise ValueError(f"to_compute_mask {tuple(m.shape)} does not match input_ids {(B, L)}")
+            cnt = m.sum(1)
+            Tc = int(cnt[0])
+            if Tc == 0 or not bool((cnt == Tc).all()):
+                raise ValueError("to_compute_mask must select the same, non-zero number of tokens in every sequence")
+            pos = m.nonzero()[:, 1].view(B, Tc).to(torch.int32).contiguous()
+            ids_c = ids[m].view(B, Tc).contiguous()
+            abi.check(self._lib.mmada_forward_cached(self._handle, ent.idx, ids_c.data_ptr(), pos.data_ptr(), B, L, Tc,
+                                                     int(bool(getattr(self, "use_cache", False))), st), "mmada_forward_cached")
+        self._shape, self._split, self._consumed = None, None, None  # no plain forward is resident any more
+
+    def cache_head_rows(self, cat, rows: torch.Tensor, col_begin: int, col_end: int,
+                        out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Rows (b*L + l) x columns [col_begin, col_end) of logit_cache[cat] (model/modeling_llada.py:1406-1413)."""
+        ent = getattr(self, "_cache", {}).get(cat)
+        if ent is None:
+            raise KeyError(f"no cache {cat!r}")
+        rows = rows.to(device=self.device, dtype=torch.int32).contiguous()
+        if out is None:
+            out = torch.empty((rows.numel(), col_end - col_begin), dtype=torch.bfloat16, device=self.device)
+        elif out.shape != (rows.numel(), col_end - col_begin) or out.dtype != torch.bfloat16 or not out.is_contiguous():
+            raise ValueError("cache_head_rows: `out` must be a contiguous bf16 [R, col_end-col_begin] tensor")
+        abi.check(self._lib.mmada_cache_head_rows(self._handle, ent.idx, rows.data_ptr(), rows.numel(), col_begin, col_end,
+                                                  out.data_ptr(), abi.stream_ptr()), "mmada_cache_head_rows")
+        return out
 
     def eval(self):
         return self

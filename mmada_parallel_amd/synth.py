@@ -122,6 +122,29 @@ def synthetic_job(height: int = 512, width: int = 512, text_gen_length: int = 25
 
 # ---- MAGVITv2 decoder of MMaDA-Parallel-M --------------------------------------------------------
 # Defaults of VQGANDecoder.__init__ (MMaDA-Parallel-M/models/modeling_magvitv2.py:278-287); level 0 = full resolution.
+def dllm_cache_script():
+    """The call sequence of the fixture (shared with the tests): a prime call, then compute-mask steps on changed ids.
+    Returns [(cat, ids, mask-or-None)]; B = 1 (the reference's rotary q_mask indexes one sequence, :714-716)."""
+    job = synthetic_job(height=64, width=64, text_gen_length=16, prompt_len=8, uncond_prompt_len=4, in_height=64,
+                        in_width=64, seed=1)  # the tiny job of the forward fixtures
+    ids0 = job["input_ids"].clone()
+    L = ids0.shape[1]
+    ts, te = job["text_start"], job["text_end"]
+    g = torch.Generator().manual_seed(11)
+    ids1 = ids0.clone()
+    ids1[0, ts:ts + 6] = torch.randint(0, 1000, (6,), generator=g)          # six text tokens get unmasked
+    m1 = torch.zeros(1, L, dtype=torch.bool)
+    m1[0, ts:te] = True                                                    # recompute the text span ...
+    m1[0, job["image_start"] + 1:job["image_start"] + 4] = True            # ... and three image tokens
+    ids2 = ids1.clone()
+    ids2[0, job["image_start"] + 1] = TEXT_VOCAB + 77                # one image token committed
+    m2 = torch.zeros(1, L, dtype=torch.bool)
+    m2[0, job["image_start"]:job["image_start"] + 9] = True
+    m2[0, te - 3:te] = True
+    return [("cond", ids0, None), ("cond", ids1, m1), ("cond", ids2, m2), ("other", ids1, None), ("other", ids2, m2)]
+
+
+
 VQ_CFG_M = dict(ch=128, ch_mult=[1, 1, 2, 2, 4], num_res_blocks=[4, 4, 3, 4, 3], z_channels=13, out_ch=3)
 VQ_CFG_TINY = dict(ch=128, ch_mult=[1, 2], num_res_blocks=[1, 2], z_channels=13, out_ch=3)
 # Defaults of VQGANEncoder.__init__ (modeling_magvitv2.py:62-73)

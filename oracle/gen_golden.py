@@ -16,6 +16,9 @@ once per class, <name>.<synth.host_isa()>.npz; this script writes the file of th
                      sampler passes to every model call + final outputs — generators/parallel_generator.py:102-368
   sampler_noisy.npz  the same at temperature 1.0 / text_temperature 0.7 with every draw taken from a seeded CPU generator
   e2e_tiny.*.npz     generate_ti2ti with the real tiny model at temperature 0: ids at every model call + outputs
+  dllm_cache.*.npz   LLaDAModelLM.forward(use_cache=True, to_compute_mask=..., cat=...) on the tiny model: a prime call and
+                     compute-mask steps on changed ids, two cache keys, with and without caching(True): logit slices +
+                     arg-max of the returned logit cache — model/modeling_llada.py:593-600,929-940,1244-1245,1406-1426
   logconf_table.npy  torch.log(p + 1e-10) in bf16 for every non-negative bf16 p (parallel_generator.py:36)
   t2i_traj.npz       generate_image (A text-to-image MaskGIT sampler) driven by the same kind of stub model, with and
                      without CFG, temperature 0 and 1 (seeded CPU generator) — generators/image_generation_generator.py
@@ -219,6 +222,37 @@ def gen_e2e():
     d = compute_e2e()
     np.savez_compressed(os.path.join(OUT, f"e2e_tiny.{synth.host_isa()}.npz"), **d)
     print(f"e2e_tiny.{synth.host_isa()}: {d['calls'].shape[0]} model calls; vq[:8]={d['vq'][:8].tolist()}")
+
+
+# ---- dLLM cache: LLaDAModelLM.forward(use_cache=True, to_compute_mask=..., cat=...) on the tiny model -----------------------
+def compute_dllm_cache() -> dict:
+    """Runs the unmodified reference: caching(True), then the script; also the same first two calls with the blocks'
+    use_cache flag left off (queries then take the LAST Tc rotary positions, modeling_llada.py:421-425)."""
+    from model.modeling_llada import LLaDAModelLM
+
+    model = build_reference_model(synth.CFG_TINY, synthetic_sd())
+    out = {}
+
+    def run(tag, script):
+        for n, (cat, ids, m) in enumerate(script):
+            with torch.no_grad():
+                lg = LLaDAModelLM.forward(model, input_ids=ids, use_cache=True, to_compute_mask=m, cat=cat).logits
+            out[f"{tag}{n}_argmax"] = lg[0].argmax(-1).numpy().astype(np.int32)
+            out[f"{tag}{n}_img"] = bits(lg[0, :, synth.TEXT_VOCAB:synth.TEXT_VOCAB + 256])
+            out[f"{tag}{n}_txt"] = bits(lg[0, :, :256])
+
+    model.caching(True)
+    run("on", synth.dllm_cache_script())
+    model.caching(False)          # clears the caches too (:598-600)
+    run("off", synth.dllm_cache_script()[:2])
+    model.empty_cache()
+    return out
+
+
+def gen_dllm_cache():
+    d = compute_dllm_cache()
+    np.savez_compressed(os.path.join(OUT, f"dllm_cache.{synth.host_isa()}.npz"), **d)
+    print(f"dllm_cache.{synth.host_isa()}: {len(d) // 3} calls")
 
 
 # ---- M variant: MMadaModelLM.interleave_generate driven by stub logits and per-call seeded RNG draws ------------------
@@ -603,3 +637,4 @@ if __name__ == "__main__":
     gen_sampler_noisy()
     gen_forward()
     gen_e2e()
+    gen_dllm_cache()

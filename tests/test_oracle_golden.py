@@ -142,6 +142,54 @@ def test_e2e_tiny_matches_reference():
         assert torch.equal(got[0], ref[0]) and (got == ref).float().mean() >= 0.6
 
 
+def _check_dllm_cache(z, exact):
+    """oracle/llada_oracle.py forward_logits_cached replayed over the fixture's script (oracle/gen_golden.py
+    dllm_cache_script) must return the reference's logit cache after every call."""
+    sd, cfg = tiny_sd(), synth.CFG_TINY
+    for tag, enable, script in (("on", True, synth.dllm_cache_script()), ("off", False, synth.dllm_cache_script()[:2])):
+        cache = llada_oracle.DllmCache(cfg["n_layers"])
+        cache.caching(enable)
+        for n, (cat, ids, m) in enumerate(script):
+            lg = llada_oracle.forward_logits_cached(sd, cfg, ids, cache, to_compute_mask=m, cat=cat)
+            img = lg[0, :, synth.TEXT_VOCAB:synth.TEXT_VOCAB + 256]
+            txt = lg[0, :, :256]
+            if exact:
+                assert torch.equal(bits(img), torch.from_numpy(z[f"{tag}{n}_img"])), f"{tag}{n} img"
+                assert torch.equal(bits(txt), torch.from_numpy(z[f"{tag}{n}_txt"])), f"{tag}{n} txt"
+                assert torch.equal(lg[0].argmax(-1).int(), torch.from_numpy(z[f"{tag}{n}_argmax"])), f"{tag}{n} argmax"
+            else:
+                for got, key in ((img, "img"), (txt, "txt")):
+                    ref = from_bits(z[f"{tag}{n}_{key}"]).float()
+                    assert (got.float() - ref).abs().mean() <= 2.0 ** -7 * ref.abs().max(), f"{tag}{n} {key}"
+                assert (lg[0].argmax(-1).int() == torch.from_numpy(z[f"{tag}{n}_argmax"])).float().mean() >= 0.9
+
+
+def test_dllm_cache_matches_reference():
+    """LLaDAModelLM.forward(use_cache=True, to_compute_mask=..., cat=...): live reference (bit for bit) where it is
+    mounted, the committed recording of this host class bit for bit, other classes' recordings by tolerance."""
+    live = _live_reference()
+    if live is not None:
+        _check_dllm_cache(live.compute_dllm_cache(), exact=True)
+    z, same = golden_float("dllm_cache")
+    _check_dllm_cache(z, exact=same)
+
+
+def test_dllm_cache_oracle_properties():
+    """Size-independent properties of the restatement: a step whose mask covers every token equals a plain forward; a step
+    on unchanged ids leaves the cached logits of the untouched rows exactly as they were."""
+    sd, cfg = tiny_sd(), synth.CFG_TINY
+    (_, ids0, _), (_, ids1, m1) = synth.dllm_cache_script()[:2]
+    cache = llada_oracle.DllmCache(cfg["n_layers"])
+    cache.caching(True)
+    full0 = llada_oracle.forward_logits_cached(sd, cfg, ids0, cache, cat="c").clone()
+    assert torch.equal(full0, llada_oracle.forward_logits(sd, cfg, ids0))
+    lg = llada_oracle.forward_logits_cached(sd, cfg, ids1, cache, to_compute_mask=m1, cat="c")
+    assert torch.equal(lg[~m1], full0[~m1])
+    allm = torch.ones_like(m1)
+    lg_all = llada_oracle.forward_logits_cached(sd, cfg, ids1, cache, to_compute_mask=allm, cat="c")
+    assert torch.equal(lg_all, llada_oracle.forward_logits(sd, cfg, ids1))
+
+
 def test_image_probs_against_torch_ops():
     # parallel_generator.py:282-295 evaluated with the reference's own torch ops on seeded random logits
     torch.manual_seed(3)
