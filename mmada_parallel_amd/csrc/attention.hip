@@ -56,14 +56,6 @@ struct AttnArgs {
     int xcd_pairs, nq;  // XCD-aware 1-D grid: (batch, head) pairs per XCD and query tiles per pair (0: plain 3-D grid)
 };
 
-// VAR: experimental loop orders, selected by MMADA_ATTN_VARIANT (0 = production).  Every variant performs the same
-// arithmetic in the same order per accumulator (bit-identical results); they differ in how the soft-max VALU work is placed
-// relative to the matrix instructions.
-//   1: s_setprio 1 around the two MFMA clusters (guide T5)
-//   2: keys [0,32) exponentiated first, their P·V issued before keys [32,64) are exponentiated (compiler-scheduled)
-//   3: as 2, with sched_group_barrier pinning 1 MFMA : 1 LDS read : 8 VALU through the first P·V half
-//   4: 3 + 1
-template <int VAR>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -138,7 +130,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
         f32x16 s0, s1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-        if constexpr (VAR == 1 || VAR == 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int ch = ((2 * s + hi) ^ ksw) << 4;
@@ -147,7 +138,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qf[s], s0, 0, 0, 0);
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka1, qf[s], s1, 0, 0, 0);
         }
-        if constexpr (VAR == 1 || VAR == 4) __builtin_amdgcn_s_setprio(0);
         // keys past L (only in the last tile) get -inf; select, not arithmetic, so garbage K rows cannot leak NaN
         if (kt * KB + KB > a.L) {
             const int kbase = kt * KB + 4 * hi;
@@ -159,7 +149,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
             }
         }
         // ---- online softmax (fp32, log2 domain); lane and lane^32 share a query ----
-        float mxa = fmax_nc(s0[0], s1[0]), mxb = fmax_nc(s0[1], s1[1]);  // two chains: shorter dependency depth
+        // two chains (shorter dependency depth), each STARTED by a compiler-visible fmaxf: hipcc inserts the wait states an
+        // MFMA result needs before a VALU may read it only for instructions it can see (guide §5.7); the asm v_max3 ops depend
+        // on these two and therefore come later.  (A loop order that put asm maxima right behind the MFMAs read stale scores.)
+        float mxa = fmaxf(s0[0], s1[0]), mxb = fmaxf(s0[1], s1[1]);
 #pragma unroll
         for (int r = 2; r < 16; r += 2) {
             mxa = max3f(mxa, s0[r], s1[r]);
@@ -177,90 +170,36 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                 for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
             m_run = m_new;
         }
-        constexpr bool PRIO = VAR == 1 || VAR == 4, SPLIT = VAR >= 2;
         float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(s0[r] * a.scale_log2e - m_run);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r] * a.scale_log2e - m_run);
+            psum += s0[r] + s1[r];
+        }
+        l_run += psum;
+
+        // P -> bf16 B-operand fragments: pb[t][s2] = P[q][keys of accumulator regs 8*s2 .. 8*s2+7 of tile t]
         bf16x8 pb[2][2];
-        if constexpr (!SPLIT) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s0[r] = __builtin_amdgcn_exp2f(s0[r] * a.scale_log2e - m_run);
-                s1[r] = __builtin_amdgcn_exp2f(s1[r] * a.scale_log2e - m_run);
-                psum += s0[r] + s1[r];
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                pb[0][s2][j] = (__bf16)s0[8 * s2 + j];
+                pb[1][s2][j] = (__bf16)s1[8 * s2 + j];
             }
-            l_run += psum;
 
-            // P -> bf16 B-operand fragments: pb[t][s2] = P[q][keys of accumulator regs 8*s2 .. 8*s2+7 of tile t]
+        // ---- O^T += V^T · P^T ----
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
+        for (int db = 0; db < 4; ++db) {
+            const char* vrow = Vt + (db * 32 + ql) * 128;  // swizzle of row db*32+ql does not depend on db
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    pb[0][s2][j] = (__bf16)s0[8 * s2 + j];
-                    pb[1][s2][j] = (__bf16)s1[8 * s2 + j];
-                }
-
-            // ---- O^T += V^T · P^T ----
-            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const char* vrow = Vt + (db * 32 + ql) * 128;  // swizzle of row db*32+ql does not depend on db
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const bf16x8 va = *(const bf16x8*)(vrow + (((4 * t + 2 * s2 + hi) ^ vsw) << 4));
-                        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[t][s2], o[db], 0, 0, 0);
-                    }
-            }
-            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-        } else {
-            // keys [0,32): exponentiate, convert, and put their P·V on the matrix pipe ...
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s0[r] = __builtin_amdgcn_exp2f(s0[r] * a.scale_log2e - m_run);
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pb[0][s2][j] = (__bf16)s0[8 * s2 + j];
-            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const char* vrow = Vt + (db * 32 + ql) * 128;
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 va = *(const bf16x8*)(vrow + (((2 * s2 + hi) ^ vsw) << 4));
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[0][s2], o[db], 0, 0, 0);
+                    const bf16x8 va = *(const bf16x8*)(vrow + (((4 * t + 2 * s2 + hi) ^ vsw) << 4));
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[t][s2], o[db], 0, 0, 0);
                 }
-            }
-            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-            // ... while keys [32,64) are exponentiated (same sum order as the unsplit loop: psum += s0[r] + s1[r])
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                s1[r] = __builtin_amdgcn_exp2f(s1[r] * a.scale_log2e - m_run);
-                psum += s0[r] + s1[r];
-            }
-            l_run += psum;
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pb[1][s2][j] = (__bf16)s1[8 * s2 + j];
-            if constexpr (VAR >= 3) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // DS read
-                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);  // VALU
-                }
-            }
-            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int db = 0; db < 4; ++db) {
-                const char* vrow = Vt + (db * 32 + ql) * 128;
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const bf16x8 va = *(const bf16x8*)(vrow + (((4 + 2 * s2 + hi) ^ vsw) << 4));
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[1][s2], o[db], 0, 0, 0);
-                }
-            }
-            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
     }
 
@@ -289,16 +228,9 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     if (Lkv % 64 || Lkv < L) return mm_fail("attention: Lkv=%d must be a multiple of 64 and >= L=%d", Lkv, L);
     if (Hq % Hkv) return mm_fail("attention: n_heads %% n_kv_heads != 0");
     if (q_begin < 0 || (q_begin & 31) || q_begin >= Lq_rows) return mm_fail("attention: bad q_begin=%d", q_begin);
-    // MMADA_ATTN_VARIANT is read on every launch (tools/attn_sweep.py switches it inside one process)
-    const char* ve = getenv("MMADA_ATTN_VARIANT");
-    const int vv = ve ? atoi(ve) : 0, var = vv >= 0 && vv <= 4 ? vv : 0;
-    typedef void (*kern_t)(AttnArgs);
-    static const kern_t kerns[5] = {attn_fwd_kernel<0>, attn_fwd_kernel<1>, attn_fwd_kernel<2>, attn_fwd_kernel<3>, attn_fwd_kernel<4>};
-    const kern_t kern = kerns[var];
     static bool attr_set = false;
     if (!attr_set) {
-        for (int i = 0; i < 5; ++i)
-            MM_CHECK_HIP(hipFuncSetAttribute((const void*)kerns[i], hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
+        MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
         attr_set = true;
     }
     AttnArgs a;
@@ -312,10 +244,10 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     static const bool xcd_aware = [] { const char* e = getenv("MMADA_ATTN_XCD"); return !(e && e[0] == '0'); }();
     if (xcd_aware && pairs % 8 == 0) {
         a.xcd_pairs = pairs / 8; a.nq = nq;
-        hipLaunchKernelGGL(kern, dim3(nq * pairs), dim3(256), ATT_LDS, s, a);
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3(nq * pairs), dim3(256), ATT_LDS, s, a);
     } else {
         a.xcd_pairs = 0; a.nq = nq;
-        hipLaunchKernelGGL(kern, dim3(nq, Hq, B), dim3(256), ATT_LDS, s, a);
+        hipLaunchKernelGGL(attn_fwd_kernel, dim3(nq, Hq, B), dim3(256), ATT_LDS, s, a);
     }
     MM_CHECK_HIP(hipGetLastError());
     return 0;
