@@ -275,6 +275,34 @@ int mmada_vq_create_encoder(const mmada_vq_cfg* cfg, mmada_vq** out);
  * [B, (H/f)*(W/f), z_channels], the pre-quantisation encoder output (parity tap). */
 int mmada_vq_get_code(mmada_vq* h, const float* pixel_values, int B, int H, int W, void* workspace,
                       size_t workspace_bytes, int64_t* indices_out, float* z_out, void* stream);
+/* ---- A variant: diffusers.VQModel (MMaDA-Parallel-A/utils/image_utils.py:13-75 decode_vq_to_image, :159-173
+ * encode_img_with_breaks; loaded at inference.py:94-96).  The class itself lives in the third-party package
+ * diffusers==0.34.0 (requirements pin), which is NOT vendored under /root/reference: this restates its published
+ * architecture (autoencoders/vq_model.py VQModel, autoencoders/vae.py Encoder / Decoder / VectorQuantizer, ResnetBlock2D,
+ * UNetMidBlock2D + Attention with one head, Downsample2D(padding=0) / Upsample2D(nearest), GroupNorm eps 1e-6, SiLU) on the
+ * kernels of the MAGVITv2 path — parity UNPINNED (no golden vectors can be produced offline).  Handles from
+ * mmada_vq_create_vqmodel are used with mmada_vq_bind (checkpoint keys of VQModel: "decoder.up_blocks.0.resnets.1.
+ * conv_shortcut.weight", "encoder.down_blocks.0.downsamplers.0.conv.bias", "decoder.mid_block.attentions.0.to_q.weight",
+ * "quant_conv.weight", "post_quant_conv.bias", "quantize.embedding.weight", ...), mmada_vq_workspace_bytes,
+ * mmada_vq_decode_code (decode(indices, force_not_quantize=True, shape=...) with lookup_from_codebook: codebook rows ->
+ * post_quant_conv -> Decoder; hz*wz need not be a multiple of 32 without mid-block attention) and mmada_vq_get_code
+ * (encode -> latents, then VectorQuantizer's nearest codebook row: z_out = the latents [B, hz*wz, vq_embed_dim]). */
+typedef struct mmada_vqmodel_cfg {   /* VQModel config.json */
+    int32_t n_levels;                /* len(block_out_channels) <= 8; scale factor 2^(n_levels-1) */
+    int32_t block_out_channels[8];   /* multiples of 128, <= 1024 */
+    int32_t layers_per_block;
+    int32_t latent_channels;
+    int32_t vq_embed_dim;            /* = latent_channels when the config leaves it null */
+    int32_t num_vq_embeddings;
+    int32_t image_channels;          /* in_channels == out_channels */
+    int32_t mid_block_add_attention;
+    int32_t norm_num_groups;         /* must be 32 */
+} mmada_vqmodel_cfg;
+int mmada_vq_create_vqmodel(const mmada_vqmodel_cfg* cfg, int encoder, mmada_vq** out);
+/* VectorQuantizer.forward's index: argmin_j cdist(z, embedding)[., j] (first minimum) for n latent rows z [n, vq_embed_dim]
+ * (NHWC); either network's handle works once "quantize.embedding.weight" is bound. */
+int mmada_vq_nearest_code(mmada_vq* h, const float* z_nhwc, int64_t n, int64_t* indices_out, void* stream);
+
 /* Kernel-level entry points (parity tests).  NHWC fp32; w_packed = weight.permute(0,2,3,1) ([Cout][k*k][Cin]);
  * upsample > 0 folds F.interpolate(scale_factor=2, mode="nearest") in front of the convolution (Upsample.forward),
  * upsample < 0 is Downsample.forward (F.pad(x,(0,1,0,1)) + 3x3 stride 2, common_modules.py:83-90);

@@ -11,5 +11,6 @@ from .generators.mmu_generator import mmu_generate, mmu_generate_fast  # noqa: F
 from .generators.t2i_generator import t2i_generate, t2i_generate_decoding_stepwise  # noqa: F401
 from .mmada import MMadaModelLM  # noqa: F401
 from .vq import MAGVITv2  # noqa: F401
+from .vqmodel import VQModel  # noqa: F401
 
-__all__ = ["LLaDAForMultiModalGeneration", "LLaDAConfigLite", "generate_ti2ti", "generate_ti2ti_stepwise", "interleave_generate", "cosine_schedule", "MAGVITv2", "generate_image", "mmu_generate", "mmu_generate_fast", "t2i_generate", "t2i_generate_decoding_stepwise", "MMadaModelLM"]
+__all__ = ["LLaDAForMultiModalGeneration", "LLaDAConfigLite", "generate_ti2ti", "generate_ti2ti_stepwise", "interleave_generate", "cosine_schedule", "MAGVITv2", "generate_image", "mmu_generate", "mmu_generate_fast", "t2i_generate", "t2i_generate_decoding_stepwise", "MMadaModelLM", "VQModel"]

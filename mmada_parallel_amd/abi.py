@@ -74,6 +74,8 @@ SIGNATURES = {
     "mmada_vq_create": (c_int, [c_void_p, C.POINTER(c_void_p)]),
     "mmada_vq_create_encoder": (c_int, [c_void_p, C.POINTER(c_void_p)]),
     "mmada_vq_get_code": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p]),
+    "mmada_vq_create_vqmodel": (c_int, [c_void_p, c_int, C.POINTER(c_void_p)]),
+    "mmada_vq_nearest_code": (c_int, [c_void_p, c_void_p, C.c_int64, c_void_p, c_void_p]),
     "mmada_vq_destroy": (None, [c_void_p]),
     "mmada_vq_bind": (c_int, [c_void_p, C.c_char_p, c_void_p, C.c_int64, c_void_p]),
     "mmada_vq_num_unbound": (c_int, [c_void_p]),

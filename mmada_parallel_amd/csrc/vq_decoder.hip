@@ -370,6 +370,57 @@ __global__ void lfq_index_kernel(const float* __restrict__ z, int64_t* __restric
 }
 
 // pixel_values [B, C, HW] -> [B, HW, C]
+// ---- diffusers VQModel quantizer (A variant): a learned codebook [n_embed, D] instead of the lookup-free bit code ----
+// VectorQuantizer.get_codebook_entry: z_q = embedding(indices).view(B, h, w, D) — which IS the NHWC layout used here
+__global__ void codebook_gather_kernel(const int64_t* __restrict__ idx, const float* __restrict__ cb, float* __restrict__ out,
+                                       long long n, int D, int n_embed) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * D) return;
+    const long long p = i / D;
+    long long id = idx[p];
+    id = id < 0 ? 0 : (id >= n_embed ? n_embed - 1 : id);  // torch would raise; keep the device safe
+    out[i] = cb[id * D + (i - p * D)];
+}
+
+// VectorQuantizer.forward: min_encoding_indices = argmin_j cdist(z, E)[., j].  torch.cdist (p = 2, > 25 rows) evaluates
+// sqrt(clamp_min(|z|^2 + |e_j|^2 - 2 z·e_j, 0)) through one matmul; this kernel forms the same three terms in fp32 and
+// takes the FIRST index of the minimum like torch.argmin.  One workgroup per latent row, codes strided over the threads.
+__global__ __launch_bounds__(256) void codebook_argmin_kernel(const float* __restrict__ z, const float* __restrict__ cb,
+                                                              int64_t* __restrict__ idx, int D, int n_embed) {
+    extern __shared__ float zrow[];  // D floats, then 256 (dist, index) pairs
+    float* sd = zrow + D;
+    int* si = (int*)(sd + 256);
+    const long long row = blockIdx.x;
+    float xn = 0.f;
+    for (int c = threadIdx.x; c < D; c += 256) zrow[c] = z[row * D + c];
+    __syncthreads();
+    for (int c = 0; c < D; ++c) xn = fmaf(zrow[c], zrow[c], xn);
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int j = threadIdx.x; j < n_embed; j += 256) {
+        const float* e = cb + (size_t)j * D;
+        float dot = 0.f, yn = 0.f;
+        for (int c = 0; c < D; ++c) {
+            const float ev = e[c];
+            dot = fmaf(-2.0f * zrow[c], ev, dot);
+            yn = fmaf(ev, ev, yn);
+        }
+        const float d = sqrtf(fmaxf(dot + xn + yn, 0.f));
+        if (d < best) { best = d; bi = j; }  // j ascending per thread: the first minimum is kept
+    }
+    sd[threadIdx.x] = best; si[threadIdx.x] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (threadIdx.x < o) {
+            const float d2 = sd[threadIdx.x + o];
+            const int i2 = si[threadIdx.x + o];
+            if (d2 < sd[threadIdx.x] || (d2 == sd[threadIdx.x] && i2 < si[threadIdx.x])) { sd[threadIdx.x] = d2; si[threadIdx.x] = i2; }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) idx[row] = si[0];
+}
+
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, long long HW, long long total) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
@@ -455,6 +506,10 @@ struct mmada_vq {
     std::vector<std::vector<ResP>> up;  // [level][block]   (decoder: up.*, encoder: down.*)
     std::vector<ConvP> upsample;        // [level] decoder: up.{l}.upsample.conv (l > 0); encoder: down.{l}.downsample.conv
     bool encoder = false;               // encoder: conv_in takes cfg.out_ch image channels, post_quant = quant_conv
+    // diffusers VQModel flavour (A variant, mmada_vq_create_vqmodel): learned codebook, optional mid-block attention
+    bool vqmodel = false, mid_attn = true;
+    float* codebook = nullptr;          // [n_embed, embed_dim]
+    int n_embed = 0, embed_dim = 0;
     std::map<std::string, Slot> slots;
     std::vector<float*> owned;
 };
@@ -471,13 +526,13 @@ void reg_norm(mmada_vq* h, const std::string& p, NormP& n, int c) {
     h->slots[p + ".weight"] = Slot{&n.g, c, 0, 0, 0, false};
     h->slots[p + ".bias"] = Slot{&n.b, c, 0, 0, 0, false};
 }
-void reg_res(mmada_vq* h, const std::string& p, ResP& r, int ci, int co) {
+void reg_res(mmada_vq* h, const std::string& p, ResP& r, int ci, int co, const char* shortcut = "nin_shortcut") {
     reg_norm(h, p + ".norm1", r.n1, ci);
     reg_conv(h, p + ".conv1", r.c1, co, ci, 3);
     reg_norm(h, p + ".norm2", r.n2, co);
     reg_conv(h, p + ".conv2", r.c2, co, co, 3);
     r.has_nin = ci != co;
-    if (r.has_nin) reg_conv(h, p + ".nin_shortcut", r.nin, co, ci, 1);
+    if (r.has_nin) reg_conv(h, p + "." + shortcut, r.nin, co, ci, 1);
 }
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -569,6 +624,13 @@ struct Runner {
         return conv(r.c2, t1, x, x, H, W, 0);
     }
 };
+
+int launch_nearest_code(const mmada_vq* h, const float* z, long long n, int64_t* idx, hipStream_t s) {
+    const size_t lds = (size_t)h->embed_dim * sizeof(float) + 256 * (sizeof(float) + sizeof(int));
+    hipLaunchKernelGGL(codebook_argmin_kernel, dim3((unsigned)n), dim3(256), lds, s, z, h->codebook, idx, h->embed_dim, h->n_embed);
+    MM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 
 }  // namespace
 
@@ -701,7 +763,7 @@ int mmada_vq_decode_code(mmada_vq* h, const int64_t* indices, int B, int hz, int
     if (!h || !indices || !workspace || !out) return mm_fail("mmada_vq_decode_code: null argument");
     if (h->encoder) return mm_fail("mmada_vq_decode_code: this handle is an encoder");
     if (B <= 0 || hz <= 0 || wz <= 0) return mm_fail("mmada_vq_decode_code: bad shape");
-    if ((hz * wz) % 32) return mm_fail("mmada_vq_decode_code: hz*wz must be a multiple of 32 (attention K tiles)");
+    if (h->mid_attn && (hz * wz) % 32) return mm_fail("mmada_vq_decode_code: hz*wz must be a multiple of 32 (attention K tiles)");
     for (const auto& kv : h->slots)
         if (!kv.second.bound) return mm_fail("mmada_vq_decode_code: tensor '%s' was never bound", kv.first.c_str());
     const Plan pl = plan_for(h, B, hz, wz);
@@ -719,13 +781,19 @@ int mmada_vq_decode_code(mmada_vq* h, const int64_t* indices, int B, int hz, int
     const long long npix = (long long)B * H * W;
 
     // get_codebook_entry (:208-221) -> post_quant_conv -> conv_in (:374-377)
-    hipLaunchKernelGGL(lfq_nhwc_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, indices, t1, npix, c.z_channels);
+    if (h->vqmodel) {  // VectorQuantizer.get_codebook_entry: rows of the learned codebook, already NHWC
+        const long long tot = npix * h->embed_dim;
+        hipLaunchKernelGGL(codebook_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, indices, h->codebook, t1,
+                           npix, h->embed_dim, h->n_embed);
+    } else {
+        hipLaunchKernelGGL(lfq_nhwc_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, indices, t1, npix, c.z_channels);
+    }
     MM_CHECK_HIP(hipGetLastError());
     if (r.conv(h->post_quant, t1, t2, nullptr, H, W, 0)) return 1;
     if (r.conv(h->conv_in, t2, x, nullptr, H, W, 0)) return 1;
     // middle (:380-382)
     if (r.res(h->mid1, x, t1, t2, H, W)) return 1;
-    if (r.attn(h, x, t1, attn, H, W)) return 1;
+    if (h->mid_attn && r.attn(h, x, t1, attn, H, W)) return 1;
     if (r.res(h->mid2, x, t1, t2, H, W)) return 1;
     // upsampling (:385-391)
     for (int lvl = c.n_levels - 1; lvl >= 0; --lvl) {
@@ -751,7 +819,7 @@ int mmada_vq_get_code(mmada_vq* h, const float* pixel_values, int B, int H, int 
     const int f = 1 << (c.n_levels - 1);
     if (B <= 0 || H <= 0 || W <= 0 || H % f || W % f) return mm_fail("mmada_vq_get_code: H, W must be multiples of %d", f);
     const int hz = H / f, wz = W / f;
-    if ((hz * wz) % 32) return mm_fail("mmada_vq_get_code: (H/%d)*(W/%d) must be a multiple of 32 (attention K tiles)", f, f);
+    if (h->mid_attn && (hz * wz) % 32) return mm_fail("mmada_vq_get_code: (H/%d)*(W/%d) must be a multiple of 32 (attention K tiles)", f, f);
     for (const auto& kv : h->slots)
         if (!kv.second.bound) return mm_fail("mmada_vq_get_code: tensor '%s' was never bound", kv.first.c_str());
     const Plan pl = plan_for(h, B, hz, wz);
@@ -780,16 +848,114 @@ int mmada_vq_get_code(mmada_vq* h, const float* pixel_values, int B, int H, int 
         }
     }
     if (r.res(h->mid1, x, t1, t2, Hc, Wc)) return 1;  // middle (:159-162)
-    if (r.attn(h, x, t1, attn, Hc, Wc)) return 1;
+    if (h->mid_attn && r.attn(h, x, t1, attn, Hc, Wc)) return 1;
     if (r.res(h->mid2, x, t1, t2, Hc, Wc)) return 1;
     if (r.norm(h->norm_out, x, t1, Hc * Wc, 1)) return 1;  // end (:165-169)
     if (r.conv(h->conv_out, t1, t2, nullptr, Hc, Wc, 0)) return 1;
     if (r.conv(h->post_quant, t2, t1, nullptr, Hc, Wc, 0)) return 1;  // quant_conv
     const long long npix = (long long)B * Hc * Wc;
+    if (h->vqmodel) {  // VQModel.encode -> latents [npix, embed_dim]; VectorQuantizer: nearest codebook row
+        if (launch_nearest_code(h, t1, npix, indices_out, s)) return 1;
+        if (z_out) MM_CHECK_HIP(hipMemcpyAsync(z_out, t1, (size_t)npix * h->embed_dim * sizeof(float), hipMemcpyDeviceToDevice, s));
+        return 0;
+    }
     hipLaunchKernelGGL(lfq_index_kernel, dim3((unsigned)((npix + 255) / 256)), dim3(256), 0, s, t1, indices_out, npix, c.z_channels);
     MM_CHECK_HIP(hipGetLastError());
     if (z_out) MM_CHECK_HIP(hipMemcpyAsync(z_out, t1, (size_t)npix * c.z_channels * sizeof(float), hipMemcpyDeviceToDevice, s));
     return 0;
+}
+
+/* ---- diffusers VQModel (A variant) ------------------------------------------------------------------------------------ */
+int mmada_vq_create_vqmodel(const mmada_vqmodel_cfg* cfg, int encoder, mmada_vq** out) {
+    if (!cfg || !out) return mm_fail("mmada_vq_create_vqmodel: null argument");
+    const int L = cfg->n_levels;
+    if (L < 1 || L > 8) return mm_fail("mmada_vq_create_vqmodel: 1..8 blocks, got %d", L);
+    if (cfg->norm_num_groups != GN_GROUPS) return mm_fail("mmada_vq_create_vqmodel: norm_num_groups must be %d", GN_GROUPS);
+    if (cfg->layers_per_block < 1 || cfg->layers_per_block > 16) return mm_fail("mmada_vq_create_vqmodel: bad layers_per_block");
+    if (cfg->latent_channels <= 0 || cfg->latent_channels > 1024 || cfg->vq_embed_dim <= 0 || cfg->vq_embed_dim > 1024 ||
+        cfg->num_vq_embeddings <= 0 || cfg->image_channels <= 0 || cfg->image_channels > 16)
+        return mm_fail("mmada_vq_create_vqmodel: bad latent_channels / vq_embed_dim / num_vq_embeddings / image_channels");
+    for (int i = 0; i < L; ++i)
+        if (cfg->block_out_channels[i] <= 0 || cfg->block_out_channels[i] % 128 || cfg->block_out_channels[i] > 1024)
+            return mm_fail("mmada_vq_create_vqmodel: block_out_channels[%d]=%d must be a multiple of 128 up to 1024 "
+                           "(GroupNorm(32) over float4 columns)", i, cfg->block_out_channels[i]);
+    mmada_vq* h = new mmada_vq();
+    h->vqmodel = true;
+    h->encoder = encoder != 0;
+    h->mid_attn = cfg->mid_block_add_attention != 0;
+    h->n_embed = cfg->num_vq_embeddings;
+    h->embed_dim = cfg->vq_embed_dim;
+    // the shared runner sizes its buffers from (ch, ch_mult): level l of the taming numbering = diffusers block l
+    h->cfg.ch = 128;
+    h->cfg.n_levels = L;
+    for (int i = 0; i < L; ++i) {
+        h->cfg.ch_mult[i] = cfg->block_out_channels[i] / 128;
+        h->cfg.num_res_blocks[i] = cfg->layers_per_block + (encoder ? 0 : 1);
+    }
+    h->cfg.z_channels = cfg->latent_channels;
+    h->cfg.out_ch = cfg->image_channels;
+    h->slots["quantize.embedding.weight"] = Slot{&h->codebook, (long long)h->n_embed * h->embed_dim, 0, 0, 0, false};
+    h->up.resize(L);
+    h->upsample.resize(L);
+    auto reg_mid = [&](int C) {
+        reg_res(h, "mid_block.resnets.0", h->mid1, C, C, "conv_shortcut");
+        if (h->mid_attn) {  // diffusers Attention with one head: GroupNorm, Linear q / k / v / out (= 1x1 convolutions), residual
+            reg_norm(h, "mid_block.attentions.0.group_norm", h->attn_norm, C);
+            reg_conv(h, "mid_block.attentions.0.to_q", h->aq, C, C, 1);
+            reg_conv(h, "mid_block.attentions.0.to_k", h->ak, C, C, 1);
+            reg_conv(h, "mid_block.attentions.0.to_v", h->av, C, C, 1);
+            reg_conv(h, "mid_block.attentions.0.to_out.0", h->aproj, C, C, 1);
+        } else {
+            h->attn_norm.c = C;
+        }
+        reg_res(h, "mid_block.resnets.1", h->mid2, C, C, "conv_shortcut");
+    };
+    if (!encoder) {  // Decoder (autoencoders/vae.py): conv_in, mid_block, up_blocks (lowest resolution first), norm, conv_out
+        reg_conv(h, "post_quant_conv", h->post_quant, cfg->latent_channels, cfg->vq_embed_dim, 1);
+        int block_in = cfg->block_out_channels[L - 1];
+        reg_conv(h, "conv_in", h->conv_in, block_in, cfg->latent_channels, 3);
+        reg_mid(block_in);
+        for (int i = 0; i < L; ++i) {
+            const int lvl = L - 1 - i, block_out = cfg->block_out_channels[lvl];
+            h->up[lvl].resize(cfg->layers_per_block + 1);
+            for (int j = 0; j <= cfg->layers_per_block; ++j) {
+                reg_res(h, "up_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), h->up[lvl][j], block_in, block_out,
+                        "conv_shortcut");
+                block_in = block_out;
+            }
+            if (i != L - 1)
+                reg_conv(h, "up_blocks." + std::to_string(i) + ".upsamplers.0.conv", h->upsample[lvl], block_in, block_in, 3);
+        }
+        reg_norm(h, "conv_norm_out", h->norm_out, block_in);
+        reg_conv(h, "conv_out", h->conv_out, cfg->image_channels, block_in, 3);
+    } else {  // Encoder: conv_in, down_blocks, mid_block, norm, conv_out; then VQModel.quant_conv
+        int block_in = cfg->block_out_channels[0];
+        reg_conv(h, "conv_in", h->conv_in, block_in, cfg->image_channels, 3);
+        for (int i = 0; i < L; ++i) {
+            const int block_out = cfg->block_out_channels[i];
+            h->up[i].resize(cfg->layers_per_block);
+            for (int j = 0; j < cfg->layers_per_block; ++j) {
+                reg_res(h, "down_blocks." + std::to_string(i) + ".resnets." + std::to_string(j), h->up[i][j], block_in, block_out,
+                        "conv_shortcut");
+                block_in = block_out;
+            }
+            if (i != L - 1)
+                reg_conv(h, "down_blocks." + std::to_string(i) + ".downsamplers.0.conv", h->upsample[i], block_in, block_in, 3);
+        }
+        reg_mid(block_in);
+        reg_norm(h, "conv_norm_out", h->norm_out, block_in);
+        reg_conv(h, "conv_out", h->conv_out, cfg->latent_channels, block_in, 3);
+        reg_conv(h, "quant_conv", h->post_quant, cfg->vq_embed_dim, cfg->latent_channels, 1);
+    }
+    *out = h;
+    return 0;
+}
+
+int mmada_vq_nearest_code(mmada_vq* h, const float* z_nhwc, int64_t n, int64_t* indices_out, void* stream) {
+    if (!h || !z_nhwc || !indices_out) return mm_fail("mmada_vq_nearest_code: null argument");
+    if (!h->vqmodel || !h->codebook) return mm_fail("mmada_vq_nearest_code: needs a VQModel handle with its codebook bound");
+    if (n <= 0) return 0;
+    return launch_nearest_code(h, z_nhwc, n, indices_out, (hipStream_t)stream);
 }
 
 /* kernel-level entry points (parity tests) */

@@ -254,3 +254,83 @@ def synthetic_vq_state_dict(cfg: dict, seed: int = 0) -> Dict[str, torch.Tensor]
         else:
             sd[name] = torch.randn(shape, generator=g) * 0.05
     return sd
+
+
+# ---- diffusers.VQModel (A variant image tokenizer): configs + seeded synthetic checkpoints -----------------------------------
+# the f16 / 8192-code layout the reference's token arithmetic assumes (vae_scale 16, VQ offset 126356 + 8192 codes)
+VQMODEL_CFG_A = dict(in_channels=3, out_channels=3, block_out_channels=[128, 256, 256, 512, 768], layers_per_block=2,
+                     latent_channels=64, num_vq_embeddings=8192, norm_num_groups=32, vq_embed_dim=None,
+                     mid_block_add_attention=False, lookup_from_codebook=True)
+VQMODEL_CFG_TINY = dict(in_channels=3, out_channels=3, block_out_channels=[128, 256], layers_per_block=1, latent_channels=8,
+                        num_vq_embeddings=64, norm_num_groups=32, vq_embed_dim=None, mid_block_add_attention=True,
+                        lookup_from_codebook=True)
+
+
+def vqmodel_param_shapes(cfg: dict) -> Dict[str, tuple]:
+    """Checkpoint keys / shapes of a diffusers VQModel with this config (Encoder, Decoder, quant convs, codebook)."""
+    bo, lpb, lat = cfg["block_out_channels"], cfg["layers_per_block"], cfg["latent_channels"]
+    emb = cfg.get("vq_embed_dim") or lat
+    L, shapes = len(bo), {}
+
+    def conv(p, co, ci, k):
+        shapes[p + ".weight"], shapes[p + ".bias"] = (co, ci, k, k), (co,)
+
+    def norm(p, c):
+        shapes[p + ".weight"], shapes[p + ".bias"] = (c,), (c,)
+
+    def res(p, ci, co):
+        norm(p + ".norm1", ci); conv(p + ".conv1", co, ci, 3); norm(p + ".norm2", co); conv(p + ".conv2", co, co, 3)
+        if ci != co:
+            conv(p + ".conv_shortcut", co, ci, 1)
+
+    def mid(p, c):
+        res(p + ".resnets.0", c, c)
+        if cfg.get("mid_block_add_attention", True):
+            norm(p + ".attentions.0.group_norm", c)
+            for n in ("to_q", "to_k", "to_v", "to_out.0"):
+                shapes[f"{p}.attentions.0.{n}.weight"], shapes[f"{p}.attentions.0.{n}.bias"] = (c, c), (c,)
+        res(p + ".resnets.1", c, c)
+
+    conv("encoder.conv_in", bo[0], cfg["in_channels"], 3)
+    cin = bo[0]
+    for i in range(L):
+        for j in range(lpb):
+            res(f"encoder.down_blocks.{i}.resnets.{j}", cin, bo[i]); cin = bo[i]
+        if i != L - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", cin, cin, 3)
+    mid("encoder.mid_block", cin)
+    norm("encoder.conv_norm_out", cin); conv("encoder.conv_out", lat, cin, 3)
+    conv("quant_conv", emb, lat, 1)
+    shapes["quantize.embedding.weight"] = (cfg["num_vq_embeddings"], emb)
+    conv("post_quant_conv", lat, emb, 1)
+    cin = bo[-1]
+    conv("decoder.conv_in", cin, lat, 3)
+    mid("decoder.mid_block", cin)
+    for i in range(L):
+        co = bo[L - 1 - i]
+        for j in range(lpb + 1):
+            res(f"decoder.up_blocks.{i}.resnets.{j}", cin, co); cin = co
+        if i != L - 1:
+            conv(f"decoder.up_blocks.{i}.upsamplers.0.conv", cin, cin, 3)
+    norm("decoder.conv_norm_out", cin); conv("decoder.conv_out", cfg["out_channels"], cin, 3)
+    return shapes
+
+
+def synthetic_vqmodel_state_dict(cfg: dict, seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded fp32 weights with fan-in scaled convolutions (activations stay O(1) through the depth) and a spread-out
+    codebook, so that nearest-code decisions are well separated."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, shp in vqmodel_param_shapes(cfg).items():
+        if k == "quantize.embedding.weight":
+            sd[k] = torch.randn(shp, generator=g)
+        elif k.endswith(".bias"):
+            sd[k] = torch.randn(shp, generator=g) * 0.02
+        elif len(shp) == 1:
+            sd[k] = 1.0 + torch.randn(shp, generator=g) * 0.05
+        else:
+            fan_in = 1
+            for v in shp[1:]:
+                fan_in *= v
+            sd[k] = torch.randn(shp, generator=g) * (1.0 / fan_in) ** 0.5
+    return sd

@@ -106,3 +106,22 @@ def test_generate_image_keep_schedule_matches_the_oracle_rule():
             else:
                 want.append(0)
         assert keep_schedule(n, steps) == want
+
+
+def test_image_processor_restatement_round_trip():
+    """utils/image_utils.py pil_to_unit_tensor / unit_tensor_to_pil = VaeImageProcessor(vae_scale_factor, do_normalize=False)
+    .preprocess / .postprocess(output_type="pil") as the reference calls them (utils/image_utils.py:39,73,165-166)."""
+    import numpy as np
+    from PIL import Image
+
+    from mmada_parallel_amd.utils import image_utils as iu
+
+    rng = np.random.default_rng(0)
+    arr = rng.integers(0, 256, size=(48, 80, 3), dtype=np.uint8)
+    x = iu.pil_to_unit_tensor(Image.fromarray(arr), 16)
+    assert x.shape == (1, 3, 48, 80) and x.dtype == torch.float32
+    assert np.array_equal(np.asarray(iu.unit_tensor_to_pil(x)[0]), arr)          # same size: no resampling, exact round trip
+    y = iu.pil_to_unit_tensor(Image.fromarray(arr[:45, :70]), 16)                # 70 x 45 -> 64 x 32 (multiples of 16)
+    assert y.shape == (1, 3, 32, 64) and 0.0 <= float(y.min()) <= float(y.max()) <= 1.0
+    toks = iu.add_break_line(list(range(6)), 2, 3, new_number=126084)
+    assert toks == [0, 1, 2, 126084, 3, 4, 5, 126084]
