@@ -223,20 +223,40 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
         T, N = job["text_end"] - job["text_start"], job["seq_len"]
         state = {}
         connect(model, 2 * B, L)
+        # pixels in -> pixels out, as inference.py runs a job (:94-96,127,218-225): the input image is tokenised by the VQ
+        # model before the sampler and the sampled codes are decoded after it.  The tokenizer is diffusers' VQModel in the
+        # reference (third-party, parity unpinned: DESIGN.md §6b); synthetic weights of the f16 / 8192-code geometry.
+        from mmada_parallel_amd import VQModel
+
+        vq_model = VQModel.from_state_dict(synth.VQMODEL_CFG_A, synth.synthetic_vqmodel_state_dict(synth.VQMODEL_CFG_A, 2), device=dev)
+        pixels = ((synth.synthetic_image(B, 512, 512, seed=5) + 1.0) * 0.5).clamp(0, 1).to(dev)   # resident in HBM
+        row = job["input_ids"][0]
+        where = torch.arange(L)
+        in_pos = ((row >= synth.TEXT_VOCAB) & (row < synth.TEXT_VOCAB + CB) & (where < job["image_start"])).nonzero()[:, 0].to(dev)
+        out_pos = torch.tensor([i for i in range(job["image_start"], job["image_start"] + N + N // job["newline_every"])
+                                if int(row[i]) != synth.NEW_LINE], device=dev)
+        assert in_pos.numel() == N and out_pos.numel() == N
 
         def run():
-            vq, _, final = generate_ti2ti(model, ids, job["text_start"], job["text_end"], job["image_start"],
+            codes = vq_model.quantize(vq_model.encode(pixels).latents)[2][2].view(B, N)      # encode_img_with_breaks
+            job_ids = ids.clone()
+            job_ids[:, in_pos] = codes + synth.TEXT_VOCAB
+            vq, _, final = generate_ti2ti(model, job_ids, job["text_start"], job["text_end"], job["image_start"],
                                           job["seq_len"], job["newline_every"], text_steps=args.text_steps,
                                           timesteps=args.timesteps, temperature=0.0, text_temperature=0.0,
                                           cfg_scale=cfg_scale, cfg_img=4.0, uncon_text=job["uncon_text"],
                                           uncon_image=job["uncon_image"], return_state=True)
+            # decode_vq_to_image; the one position the schedule leaves masked is a random code in the reference (A.1)
+            out_codes = (final[:, out_pos] - synth.TEXT_VOCAB).clamp(0, CB - 1).view(B, 32, 32)
+            state["pixels"] = vq_model.decode(out_codes, force_not_quantize=True).sample.clip(0, 1)
             state["final"] = final
             return final
 
         n_img = len(set(image_step_indices(args.text_steps, args.timesteps)))
         fl = job_flops(cfg, L, T, N, args.text_steps, n_img, V, CB, job if windowed else None)
         name = ("BASELINE configs[1]: MMaDA-Parallel-A 8B, 512x512, timesteps=64, text_steps=128, cfg_img=4.0, "
-                "temperature=0, L=2438, 256 forwards/image") if cfgnum == 1 else \
+                "temperature=0, L=2438, 256 forwards/image, pixels in -> pixels out (VQ encode + decode inside the step)") \
+            if cfgnum == 1 else \
                (f"BASELINE configs[4] (single-GPU form): MMaDA-Parallel-A 8B editing, batch={B}, 512x512, cfg_scale=3.0 + "
                 "cfg_img=4.0 (triple-branch CFG), timesteps=64, text_steps=128, temperature=0, L=2438, 256 sequence-forwards/image")
         metric = "images/sec (512x512, 64 img + 128 text steps) MMaDA-Parallel-A 8B" + \
