@@ -237,8 +237,25 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
                                 if int(row[i]) != synth.NEW_LINE], device=dev)
         assert in_pos.numel() == N and out_pos.numel() == N
 
+        # tensor parallel: every rank needs every job's ids, but tokenising / decoding all B images on every rank would be
+        # replicated work that does not shrink with the rank count — each rank handles its own slice of the jobs and the
+        # (tiny: N int64 per job) codes are all-gathered; the decoded pixels stay on the rank that decoded them
+        share = tp > 1 and B % tp == 0
+        mine = slice(rank * (B // tp), (rank + 1) * (B // tp)) if share else slice(0, B)
+
         def run():
-            codes = vq_model.quantize(vq_model.encode(pixels).latents)[2][2].view(B, N)      # encode_img_with_breaks
+            codes = vq_model.quantize(vq_model.encode(pixels[mine]).latents)[2][2].view(-1, N)   # encode_img_with_breaks
+            if share:
+                import torch.distributed as dist
+
+                if dist.get_backend() == "gloo":   # the one-GPU test rig: gloo gathers host tensors
+                    parts = [torch.empty((B // tp, N), dtype=codes.dtype) for _ in range(tp)]
+                    dist.all_gather(parts, codes.cpu())
+                    codes = torch.cat(parts, 0).to(dev)
+                else:
+                    allc = torch.empty((B, N), dtype=codes.dtype, device=dev)
+                    dist.all_gather_into_tensor(allc, codes.contiguous())
+                    codes = allc
             job_ids = ids.clone()
             job_ids[:, in_pos] = codes + synth.TEXT_VOCAB
             vq, _, final = generate_ti2ti(model, job_ids, job["text_start"], job["text_end"], job["image_start"],
@@ -247,7 +264,7 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
                                           cfg_scale=cfg_scale, cfg_img=4.0, uncon_text=job["uncon_text"],
                                           uncon_image=job["uncon_image"], return_state=True)
             # decode_vq_to_image; the one position the schedule leaves masked is a random code in the reference (A.1)
-            out_codes = (final[:, out_pos] - synth.TEXT_VOCAB).clamp(0, CB - 1).view(B, 32, 32)
+            out_codes = (final[mine][:, out_pos] - synth.TEXT_VOCAB).clamp(0, CB - 1).view(-1, 32, 32)
             state["pixels"] = vq_model.decode(out_codes, force_not_quantize=True).sample.clip(0, 1)
             state["final"] = final
             return final
