@@ -234,7 +234,7 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
         where = torch.arange(L)
         in_pos = ((row >= synth.TEXT_VOCAB) & (row < synth.TEXT_VOCAB + CB) & (where < job["image_start"])).nonzero()[:, 0].to(dev)
         out_pos = torch.tensor([i for i in range(job["image_start"], job["image_start"] + N + N // job["newline_every"])
-                                if int(row[i]) != synth.NEW_LINE], device=dev)
+                                if int(row[i]) != synth.NEW_LINE])  # generate_ti2ti hands the final ids back on the host
         assert in_pos.numel() == N and out_pos.numel() == N
 
         # tensor parallel: every rank needs every job's ids, but tokenising / decoding all B images on every rank would be
@@ -264,7 +264,7 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
                                           cfg_scale=cfg_scale, cfg_img=4.0, uncon_text=job["uncon_text"],
                                           uncon_image=job["uncon_image"], return_state=True)
             # decode_vq_to_image; the one position the schedule leaves masked is a random code in the reference (A.1)
-            out_codes = (final[mine][:, out_pos] - synth.TEXT_VOCAB).clamp(0, CB - 1).view(-1, 32, 32)
+            out_codes = (final[mine][:, out_pos] - synth.TEXT_VOCAB).clamp(0, CB - 1).view(-1, 32, 32).to(dev)
             state["pixels"] = vq_model.decode(out_codes, force_not_quantize=True).sample.clip(0, 1)
             state["final"] = final
             return final
