@@ -5,6 +5,8 @@ O=$R/gpurun_out/r02
 mkdir -p $O
 cd $R
 export GPU_MAX_HW_QUEUES=12
+# a two-block, six-step bench first: if the benchmark script itself is broken, stop before spending the GPU time
+timeout 300 python bench.py --layers 2 --text-steps 4 --timesteps 2 --no-cpu-baseline > $O/smoke_bench.json 2> $O/smoke_bench.err || { echo "smoke bench failed"; tail -5 $O/smoke_bench.err; exit 1; }
 (timeout 1100 python -m pytest tests -q -m gpu) > $O/pytest_gpu.log 2>&1; echo "suite rc=$?"
 timeout 500 python bench.py > $O/bench_config1.json 2> $O/bench_config1.err; echo "bench1 rc=$?"
 timeout 600 python bench.py --config 3 --steps 1 --warmup 1 > $O/bench_config3.json 2> $O/bench_config3.err; echo "bench3 rc=$?"
