@@ -370,14 +370,16 @@ int mmada_forward_cached(mmada_handle* h, int slot, const int64_t* ids, const in
     if (apply_carve(h, B, L, s)) return 1;
     if (pos) {
         h->L = Tc; h->Lp = ceil_to(Tc, 8); h->Lkv = ceil_to(Tc, 64); h->M = B * h->Lp;
-        if (launch_expand_pos(pos, h->posmap, B, Tc, h->Lp, L, s)) return 1;
+        if (launch_expand_pos(pos, h->posmap, B, Tc, h->Lp, L, s)) { h->M = 0; return 1; }
     }
     h->cur_W = 0; h->cur_beg = 0; h->Mcur = h->M;
     h->xn_is_final = false;
     h->xn_is_layer0 = true;
     const int d = h->cfg.d_model;
-    if (launch_embed(ids, h->wte, h->x, B, h->L, h->Lp, d, h->cfg.vocab, s, h->layers[0].attn_norm, h->xn, h->cfg.rms_eps))
+    if (launch_embed(ids, h->wte, h->x, B, h->L, h->Lp, d, h->cfg.vocab, s, h->layers[0].attn_norm, h->xn, h->cfg.rms_eps)) {
+        h->M = 0;
         return 1;
+    }
     h->cc = &c;
     h->cc_pos = pos ? h->posmap : nullptr;
     h->cc_qshift = (pos && !q_pos_from_map) ? L - Tc : -1;
@@ -392,7 +394,7 @@ int mmada_forward_cached(mmada_handle* h, int slot, const int64_t* ids, const in
     // :1409-1411; a logit row is a function of its residual row alone, so the head runs on demand: mmada_cache_head_rows)
     bf16_t* xfin = c.xfin(h->cfg.n_layers);
     if (pos) {
-        if (launch_scatter_rows(h->x, xfin, h->posmap, h->M, h->Lp, c.Lp, d, s)) return 1;
+        if (launch_scatter_rows(h->x, xfin, h->posmap, h->M, h->Lp, c.Lp, d, s)) { h->M = 0; return 1; }
     } else {
         MM_CHECK_HIP(hipMemcpyAsync(xfin, h->x, (size_t)h->M * d * 2, hipMemcpyDeviceToDevice, s));
     }
@@ -408,11 +410,22 @@ int mmada_cache_head_rows(mmada_handle* h, int slot, const int32_t* rows, int R,
     if (R <= 0) return 0;
     if (R > c.B * c.L) return mm_fail("mmada_cache_head_rows: R=%d exceeds B*L=%d", R, c.B * c.L);
     if (col_begin < 0 || col_end > h->cfg.vocab || col_begin >= col_end) return mm_fail("mmada_cache_head_rows: bad column range");
-    const Carve cv = carve_for(h, c.B, c.L);
-    if (!h->ws || cv.total > h->ws_bytes) return mm_fail("mmada_cache_head_rows: workspace too small (%zu needed)", cv.total);
     hipStream_t s = (hipStream_t)stream;
     const int d = h->cfg.d_model;
-    bf16_t* xg = (bf16_t*)(h->ws + cv.xg);
+    // staging rows for ln_f: the gather buffer of the workspace.  While a plain forward is resident its carve is live, so
+    // its own gather buffer (B*L rows of that forward) is the only region that may be written; otherwise the carve of the
+    // slot's shape applies
+    bf16_t* xg;
+    if (h->M != 0) {
+        if ((size_t)R > (size_t)h->B * h->L)
+            return mm_fail("mmada_cache_head_rows: %d rows do not fit the resident forward's gather buffer (%d x %d rows); "
+                           "ask for fewer rows per call", R, h->B, h->L);
+        xg = h->xg;
+    } else {
+        const Carve cv = carve_for(h, c.B, c.L);
+        if (!h->ws || cv.total > h->ws_bytes) return mm_fail("mmada_cache_head_rows: workspace too small (%zu needed)", cv.total);
+        xg = (bf16_t*)(h->ws + cv.xg);
+    }
     if (launch_rmsnorm_gather(c.xfin(h->cfg.n_layers), h->ln_f, xg, rows, R, c.L, c.Lp, d, h->cfg.rms_eps, s, 0, c.B * c.L))
         return 1;
     GemmArgs g{};

@@ -210,3 +210,22 @@ def test_cache_step_at_8b_shapes_vs_oracle_and_timing():
     print(f"8B-shape, 2 blocks, L={L}: full forward {t_full:.2f} ms, cache step over {Tc} tokens {t_step:.2f} ms")
     save_parity("dllm_cache_8b_shapes", rep)
     model.empty_cache()
+
+
+def test_cache_head_rows_leaves_a_resident_plain_forward_intact(tiny_model):
+    """Reading a slot's logits while a plain forward of ANOTHER shape is resident must not disturb that forward (the
+    staging rows go to the resident carve's own gather buffer)."""
+    (_, ids0, _), (_, ids1, _) = synth.dllm_cache_script()[:2]
+    L = ids0.shape[1]
+    tiny_model.caching(True)
+    tiny_model.forward_cached(ids0.to(DEV), cat="c")
+    rows1 = torch.arange(L, dtype=torch.int32, device=DEV)
+    want = tiny_model.cache_head_rows("c", rows1, 0, 512).clone()
+    tiny_model.forward_body(torch.cat([ids1, ids0], 0).to(DEV))            # B = 2 plain forward now resident
+    rows2 = torch.arange(2 * L, dtype=torch.int32, device=DEV)
+    before = tiny_model.head_rows(rows2, 0, 512).clone()
+    got = tiny_model.cache_head_rows("c", rows1, 0, 512)
+    after = tiny_model.head_rows(rows2, 0, 512)
+    assert torch.equal(got, want) and torch.equal(before, after)
+    assert torch.equal(after[L:], want)                                      # the same sequence, plain vs primed slot
+    tiny_model.empty_cache()
