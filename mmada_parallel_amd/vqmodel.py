@@ -116,7 +116,13 @@ class VQModel:
         return cls(config, sd, **kw)
 
     def to(self, device=None, *_a, **_k):
-        if device is not None and torch.device(device) != self.device and torch.device(device).type == "cuda":
+        """`.to(device)` of the reference (inference.py:95): a no-op for the device the weights already live on."""
+        if device is None or isinstance(device, torch.dtype):
+            return self
+        d = torch.device(device)
+        if d.type != "cuda":
+            raise NotImplementedError("the MI355X VQModel has no CPU path")
+        if d.index is not None and d.index != (self.device.index or 0):
             raise NotImplementedError("the weights live on the device the model was built on; pass device= at construction")
         return self
 
