@@ -400,8 +400,10 @@ def generate_ti2ti_stepwise(
         (step + 1, combined_input_ids [B, L] on the device, sampled VQ ids [B, N] of this step's image update or None,
          show)   with show == the reference's display cadence (step % 5 == 0, image steps, last step).
 
-    Decoding the ids to text / pixels (tokenizer, VQ-VAE: `vqvae`, `image_height`, `image_width`) is the caller's UI
-    work and is not done here (the VQ-VAE is third-party `diffusers` code)."""
+    Turning the yielded ids into what the UI displays is the caller's work: text through the tokenizer, and the preview of
+    an image step through `utils.decode_step_preview(sampled, masked_cells, vqvae, image_height, image_width)` (the
+    reference's decode_vq_to_image + gray overlay of the re-masked cells, app.py:310-339) — `vqvae`, `image_height` and
+    `image_width` are accepted here for signature compatibility only."""
     sched = stepwise_image_steps(text_steps)
     with torch.no_grad():
         for step, ids, info in _ti2ti_steps(model, input_ids, text_start, text_end, image_start, seq_len, newline_every,

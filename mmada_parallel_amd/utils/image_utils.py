@@ -125,3 +125,24 @@ def encode_img_with_paint(img, vqvae, *, mask_h_ratio: float = 1, mask_w_ratio: 
     m = m.reshape(-1)
     tokens = torch.where(m, torch.full_like(idx, MASK_TOKEN_ID), idx + VQ_OFFSET)
     return add_break_line(tokens.tolist(), lat_h, lat_w, NEWLINE_TOKEN_ID), vis
+
+
+def decode_step_preview(sampled_ids, masked_cells, vqvae, image_height: int = 512, image_width: int = 512):
+    """The picture the reference's streaming sampler shows after an image step (app.py:310-339): ALL sampled codes of the
+    step decoded, with a translucent gray square over every latent cell the step re-masked.
+    sampled_ids: [1, N] codes in [0, codebook_size) — the third item `generate_ti2ti_stepwise` yields;
+    masked_cells: indices in [0, N) of the cells still masked after the step (e.g. where the yielded ids are MASK)."""
+    from PIL import ImageDraw
+
+    img = decode_vq_to_image(sampled_ids[:1], None, None, image_height, image_width, vqvae)
+    cells = [int(c) for c in masked_cells]
+    if cells:
+        scale = _scale_of(vqvae)
+        gw = image_width // scale
+        ph, pw = image_height // (image_height // scale), image_width // gw
+        img = img.copy()
+        draw = ImageDraw.Draw(img, "RGBA")
+        for c in cells:
+            y, x = (c // gw) * ph, (c % gw) * pw
+            draw.rectangle([x, y, x + pw, y + ph], fill=(128, 128, 128, 120))
+    return img

@@ -147,3 +147,18 @@ def test_pixel_token_helpers_follow_the_reference_conventions():
     assert n_in + n_out == lat_h * lat_w and 0 < n_in < n_out
     cells = [t for i, t in enumerate(ptoks) if (i + 1) % (lat_w + 1)]
     assert all(t == 126336 or t - 126356 == c for t, c in zip(cells, codes))
+
+
+def test_stepwise_preview_decodes_and_marks_the_masked_cells():
+    """app.py:310-339: every sampled code decoded, a translucent gray square over each re-masked latent cell."""
+    import numpy as np
+
+    cfg = synth.VQMODEL_CFG_TINY
+    vq = VQModel.from_state_dict(cfg, synth.synthetic_vqmodel_state_dict(cfg, seed=1), device=DEV)
+    g = torch.Generator().manual_seed(9)
+    codes = torch.randint(0, cfg["num_vq_embeddings"], (1, 16 * 32), generator=g).to(DEV)
+    plain = np.asarray(iu.decode_step_preview(codes, [], vq, 32, 64)).astype(int)
+    marked = np.asarray(iu.decode_step_preview(codes, [0, 33], vq, 32, 64)).astype(int)     # cells (0,0) and (1,1), 2 x 2 pixels each
+    assert plain.shape == marked.shape == (32, 64, 3)
+    diff = (plain != marked).any(-1)
+    assert diff[:3, :3].any() and diff[2:5, 2:5].any() and not diff[8:, :].any() and not diff[:, 8:].any()
