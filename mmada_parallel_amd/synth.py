@@ -120,6 +120,27 @@ def synthetic_job(height: int = 512, width: int = 512, text_gen_length: int = 25
                 seq_len=seq_len, newline_every=newline_every)
 
 
+def paint_job(kind: str, codebook_size: int = CODEBOOK, text_vocab: int = TEXT_VOCAB, seed: int = 21, **job_kw):
+    """A TI2TI job in painting mode (inference.py:141-146 -> utils/image_utils.py encode_img_with_paint): the OUTPUT image
+    span starts partly known — the cells outside a centred rectangle keep codes ("inpainting") or only the cells inside do
+    ("outpainting") — so the sampler's unknown count starts below N.  Same layout as synthetic_job otherwise."""
+    job = synthetic_job(**job_kw)
+    ids = job["input_ids"].clone()
+    n, per = job["seq_len"], job["newline_every"]
+    rows = n // per
+    g = torch.Generator().manual_seed(seed)
+    codes = torch.randint(0, codebook_size, (n,), generator=g) + text_vocab
+    inside = torch.zeros(rows, per, dtype=torch.bool)
+    inside[rows // 4:rows - rows // 4, per // 4:per - per // 4] = True
+    known = (~inside if kind == "inpainting" else inside).reshape(-1)
+    pos = [i for i in range(job["image_start"], job["image_start"] + n + rows) if int(ids[0, i]) != NEW_LINE]
+    for j, p_ in enumerate(pos):
+        if bool(known[j]):
+            ids[0, p_] = codes[j]
+    job["input_ids"] = ids
+    return job
+
+
 # ---- MAGVITv2 decoder of MMaDA-Parallel-M (SURVEY §8f rank 1) --------------------------------------------------------
 # Defaults of VQGANDecoder.__init__ (MMaDA-Parallel-M/models/modeling_magvitv2.py:278-287); level 0 = full resolution.
 def dllm_cache_script():

@@ -14,6 +14,7 @@ once per class, <name>.<synth.host_isa()>.npz; this script writes the file of th
                      top-8) — model/modeling_xllmx_dimoo.py:41-72 + model/modeling_llada.py:1201-1415
   sampler_traj.npz   generate_ti2ti driven by a STUB model that returns seeded random bf16 logits: the ids the
                      sampler passes to every model call + final outputs — generators/parallel_generator.py:102-368
+  paint_traj.npz     the same in painting mode: the output image span starts partly known (in- / out-painting rectangle)
   sampler_noisy.npz  the same at temperature 1.0 / text_temperature 0.7 with every draw taken from a seeded CPU generator
   e2e_tiny.*.npz     generate_ti2ti with the real tiny model at temperature 0: ids at every model call + outputs
   dllm_cache.*.npz   LLaDAModelLM.forward(use_cache=True, to_compute_mask=..., cat=...) on the tiny model: a prime call and
@@ -176,6 +177,32 @@ def gen_sampler_traj():
         out[name + "_seed"] = np.array(seed)
         print(f"sampler_traj[{name}]: {len(calls)} model calls, {len(text)} text tokens")
     np.savez_compressed(os.path.join(OUT, "sampler_traj.npz"), **out)
+
+
+def gen_paint_traj():
+    """generate_ti2ti in painting mode: the output image span starts partly known (inference.py:141-146), so the image
+    branch's unknown count starts below N; stub logits, temperature 0."""
+    from tests.helpers import PAINT_CASES, paint_job
+
+    V = STUB_TEXT_VOCAB + STUB_CB
+    out = {}
+    for ci, (name, (kind, kw)) in enumerate(PAINT_CASES.items()):
+        seed = 61 + ci
+        job = paint_job(kind)
+
+        def fn(ids, call_idx, seed=seed):
+            return SimpleNamespace(logits=stub_logits(seed, call_idx, ids.shape[0], ids.shape[1], V))
+
+        calls, vq, text = run_reference_sampler(fn, job, temperature=0.0, text_temperature=0.0,
+                                                text_vocab_size=STUB_TEXT_VOCAB, codebook_size=STUB_CB, **kw)
+        out[name + "_calls"] = torch.cat(calls, 0).numpy()
+        out[name + "_vq"] = np.array(vq, np.int64)
+        out[name + "_text"] = np.array(text, np.int64)
+        out[name + "_seed"] = np.array(seed)
+        span = job["input_ids"][0, job["image_start"]:job["image_start"] + job["seq_len"] + job["seq_len"] // job["newline_every"]]
+        n_known = int(((span != synth.MASK) & (span != synth.NEW_LINE)).sum())
+        print(f"paint_traj[{name}]: {len(calls)} model calls, {n_known} of {job['seq_len']} output cells known at the start")
+    np.savez_compressed(os.path.join(OUT, "paint_traj.npz"), **out)
 
 
 def gen_sampler_noisy():
@@ -634,6 +661,7 @@ if __name__ == "__main__":
     gen_stepwise_traj()
     gen_m_traj()
     gen_sampler_traj()
+    gen_paint_traj()
     gen_sampler_noisy()
     gen_forward()
     gen_e2e()

@@ -171,3 +171,15 @@ def host_threads():
     """Oracle matmuls on the physical cores, not on every hyper-thread (oversubscription made round 1's CPU numbers 3x slow)."""
     n = os.cpu_count() or 8
     torch.set_num_threads(max(1, n if n <= 64 else n // 2))
+
+
+# painting mode (the output image span starts partly known): tests/golden/paint_traj.npz
+PAINT_CASES = {
+    "inpaint_img4": ("inpainting", dict(text_steps=8, timesteps=4, cfg_scale=0.0, cfg_img=4.0)),
+    "outpaint_both": ("outpainting", dict(text_steps=10, timesteps=5, cfg_scale=2.5, cfg_img=4.0)),
+}
+TINY_JOB_KW = dict(height=64, width=64, text_gen_length=16, prompt_len=8, uncond_prompt_len=4, in_height=64, in_width=64, seed=1)
+
+
+def paint_job(kind):
+    return synth.paint_job(kind, codebook_size=STUB_CB, text_vocab=STUB_TEXT_VOCAB, **TINY_JOB_KW)

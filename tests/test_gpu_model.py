@@ -235,6 +235,41 @@ def test_generate_stub_trajectory_bit_exact(tiny_model, name):
     assert n_fill == 1
 
 
+@pytest.mark.parametrize("name", ["inpaint_img4", "outpaint_both"])
+def test_generate_painting_mode_trajectory_bit_exact(tiny_model, name):
+    """Painting mode: the output image span starts partly known (in- / out-painting rectangle): every model call's ids must
+    equal the reference's recording, known cells are never touched (tests/golden/paint_traj.npz)."""
+    from helpers import PAINT_CASES, paint_job
+    from mmada_parallel_amd import generate_ti2ti
+
+    z = np.load(os.path.join(GOLDEN, "paint_traj.npz"))
+    calls_ref = torch.from_numpy(z[name + "_calls"])
+    kind, kw = PAINT_CASES[name]
+    job = paint_job(kind)
+    V = STUB_TEXT_VOCAB + STUB_CB
+    stub = _stubbed(tiny_model, int(z[name + "_seed"]), V)
+    old = tiny_model.config.__dict__.copy()
+    try:
+        vq, text, final = generate_ti2ti(stub, job["input_ids"].to(DEV), job["text_start"], job["text_end"],
+                                         job["image_start"], job["seq_len"], job["newline_every"], temperature=0.0,
+                                         text_temperature=0.0, uncon_text=job["uncon_text"], uncon_image=job["uncon_image"],
+                                         tokenizer=None, text_vocab_size=STUB_TEXT_VOCAB, codebook_size=STUB_CB,
+                                         return_state=True, **kw)
+    finally:
+        tiny_model.config.__dict__.update(old)
+    got = torch.cat(stub.calls, 0)
+    assert got.shape == calls_ref.shape
+    assert torch.equal(got, calls_ref), f"first differing model call: {(got != calls_ref).any(1).nonzero()[0].item()}"
+    assert text == z[name + "_text"].tolist()
+    pos = [i for i in range(job["image_start"], job["image_start"] + job["seq_len"] + job["seq_len"] // job["newline_every"])
+           if int(job["input_ids"][0, i]) != synth.NEW_LINE]
+    for j, p in enumerate(pos):
+        if int(job["input_ids"][0, p]) != synth.MASK:
+            assert int(final[0, p]) == int(job["input_ids"][0, p])
+        if int(final[0, p]) != synth.MASK:
+            assert vq[j] == int(z[name + "_vq"][j])
+
+
 # --------------------------------------------------------------------------------------------- (iii) teacher-forced e2e
 def test_teacher_forced_tiny_trajectory(tiny_model):
     """Feed the reference's recorded ids of every conditional call; compare the GPU's per-position decisions

@@ -58,6 +58,40 @@ def test_sampler_trajectory_matches_reference(name):
     assert text == z[name + "_text"].tolist()
 
 
+@pytest.mark.parametrize("name", ["inpaint_img4", "outpaint_both"])
+def test_painting_mode_trajectory_matches_reference(name):
+    """Painting mode (inference.py:141-146): the output image span starts partly known, so the image branch's unknown count
+    starts below N and the known cells must survive every re-mask."""
+    from helpers import PAINT_CASES, paint_job
+
+    z = np.load(os.path.join(GOLDEN, "paint_traj.npz"))
+    kind, kw = PAINT_CASES[name]
+    job = paint_job(kind)
+    seed = int(z[name + "_seed"])
+    V = STUB_TEXT_VOCAB + STUB_CB
+    n = [0]
+
+    def model_fn(ids):
+        n[0] += 1
+        return stub_logits(seed, n[0], ids.shape[0], ids.shape[1], V)
+
+    trace = []
+    final = generate_oracle.generate(model_fn, job["input_ids"], job["text_start"], job["text_end"], job["image_start"],
+                                     job["seq_len"], job["newline_every"], uncon_text=job["uncon_text"],
+                                     uncon_image=job["uncon_image"], text_vocab_size=STUB_TEXT_VOCAB,
+                                     codebook_size=STUB_CB, trace=trace, **kw)
+    assert torch.equal(torch.cat(trace, 0), torch.from_numpy(z[name + "_calls"]))
+    pos = [i for i in range(job["image_start"], job["image_start"] + job["seq_len"] + job["seq_len"] // job["newline_every"])
+           if int(job["input_ids"][0, i]) != synth.NEW_LINE]
+    known0 = [int(job["input_ids"][0, p]) for p in pos]
+    for j, p in enumerate(pos):
+        tok = int(final[0, p])
+        if known0[j] != synth.MASK:
+            assert tok == known0[j]                       # a known cell is never re-masked or overwritten
+        if tok != synth.MASK:
+            assert tok - STUB_TEXT_VOCAB == z[name + "_vq"][j]
+
+
 def _live_reference():
     """oracle/gen_golden.py's compute_* functions run the UNMODIFIED reference on this host; None where the reference tree
     is not mounted (GPU box)."""
