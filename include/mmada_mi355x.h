@@ -182,6 +182,13 @@ int mmada_debug_buffer(mmada_handle* h, int which, void** ptr_out, int32_t* lp_o
 int mmada_text_select(mmada_handle* h, const void* logits, const void* noisy, int B, int T, int V, int ld_logits,
                       int64_t* ids, int L, int text_start, const int32_t* k, void* scratch, void* stream);
 
+/* The same step with remasking='random' (generators/parallel_generator.py:194-198, inference.py --remasking random): the
+ * confidence that ranks the masked positions is `uniform` (device fp32 [B,T], the caller's torch.rand draw) instead of the
+ * soft-max probability; x0 is still the arg-max of `noisy` / `logits`. */
+int mmada_text_select_random(mmada_handle* h, const void* logits, const void* noisy, const float* uniform, int B, int T,
+                             int V, int ld_logits, int64_t* ids, int L, int text_start, const int32_t* k, void* scratch,
+                             void* stream);
+
 /* Image step part 1, generators/parallel_generator.py:282-295,311: dual-CFG combine with the reference's per-op
  * bf16 rounding, softmax → bf16 probabilities, first-index argmax, probability of the argmax.
  * cond/unc_text/unc_img: bf16 device [B,N,CB] (unc_* may be NULL when the matching scale == 0).

@@ -54,6 +54,8 @@ SIGNATURES = {
     "mmada_debug_buffer": (c_int, [c_void_p, c_int, C.POINTER(c_void_p), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "mmada_text_select": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int,
                                   c_void_p, c_void_p, c_void_p]),
+    "mmada_text_select_random": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int,
+                                         c_int, c_void_p, c_void_p, c_void_p]),
     "mmada_image_probs": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
                                   c_void_p, c_void_p, c_void_p, c_void_p]),
     "mmada_image_commit": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p,

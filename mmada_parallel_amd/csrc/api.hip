@@ -500,6 +500,15 @@ int mmada_text_select(mmada_handle* h, const void* logits, const void* noisy, in
                               text_start, k, scratch, h->cfg.mask_token_id, (hipStream_t)stream);
 }
 
+int mmada_text_select_random(mmada_handle* h, const void* logits, const void* noisy, const float* uniform, int B, int T,
+                             int V, int ld_logits, int64_t* ids, int L, int text_start, const int32_t* k, void* scratch,
+                             void* stream) {
+    if (!h || !logits || !uniform || !ids || !k || !scratch) return mm_fail("mmada_text_select_random: null argument");
+    if (text_start < 0 || text_start + T > L) return mm_fail("mmada_text_select_random: text span outside the sequence");
+    return launch_text_select((const bf16_t*)logits, (const bf16_t*)noisy, nullptr, 0.f, nullptr, B, T, V, ld_logits, ids, L,
+                              text_start, k, scratch, h->cfg.mask_token_id, (hipStream_t)stream, uniform);
+}
+
 int mmada_text_select_cfg(mmada_handle* h, const void* cond, const void* uncond, float text_cfg, const int32_t* x0_in,
                           int B, int T, int V, int ld_logits, int64_t* ids, int L, int text_start, const int32_t* k,
                           void* scratch, void* stream) {

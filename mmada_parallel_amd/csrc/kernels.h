@@ -83,7 +83,7 @@ int launch_text_stats_partial(const bf16_t* logits, int B, int T, int Vl, int ld
 int launch_text_commit(const void* scratch, int B, int T, int64_t* ids, int L, int text_start, const int32_t* k, hipStream_t s);
 int launch_text_select(const bf16_t* logits, const bf16_t* noisy, const bf16_t* unc, float text_cfg, const int32_t* x0_in,
                        int B, int T, int V, int ld, int64_t* ids, int L, int text_start, const int32_t* k, void* scratch,
-                       int mask_id, hipStream_t s);
+                       int mask_id, hipStream_t s, const float* rand_conf = nullptr);
 int launch_image_probs(const bf16_t* cond, const bf16_t* ut, const bf16_t* ui, int B, int N, int CB, float cfg_scale,
                        float cfg_img, bf16_t* probs_out, int32_t* argmax_out, bf16_t* pmax_out, int mvar, hipStream_t s);
 int launch_image_commit(int64_t* ids, int B, int L, const int32_t* pos_map, int N, const int32_t* sampled_in,

@@ -403,9 +403,16 @@ __global__ __launch_bounds__(1024) void image_commit_kernel(int64_t* __restrict_
 
 }  // namespace
 
+// remasking == 'random' (generators/parallel_generator.py:194-198): the confidence of a masked position is a uniform draw
+// instead of its soft-max probability; already-unmasked positions keep -inf (:203)
+__global__ void text_random_conf_kernel(double* __restrict__ conf, const float* __restrict__ u, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && conf[i] != -INFINITY) conf[i] = (double)u[i];
+}
+
 int launch_text_select(const bf16_t* logits, const bf16_t* noisy, const bf16_t* unc, float text_cfg, const int32_t* x0_in,
                        int B, int T, int V, int ld, int64_t* ids, int L, int text_start, const int32_t* k, void* scratch,
-                       int mask_id, hipStream_t s) {
+                       int mask_id, hipStream_t s, const float* rand_conf) {
     if (B <= 0 || T <= 0) return 0;
     if (ld % 8) return mm_fail("text_select: ld_logits must be a multiple of 8");
     if (T > 8192) return mm_fail("text_select: T=%d too large", T);
@@ -418,6 +425,10 @@ int launch_text_select(const bf16_t* logits, const bf16_t* noisy, const bf16_t* 
         hipLaunchKernelGGL(text_row_stats_kernel<false>, dim3(B * T), dim3(TB), 0, s, logits, noisy, unc, text_cfg, x0_in,
                            T, V, ld, ids, L, text_start, mask_id, conf, x0);
     MM_CHECK_HIP(hipGetLastError());
+    if (rand_conf) {
+        hipLaunchKernelGGL(text_random_conf_kernel, dim3((B * T + 255) / 256), dim3(256), 0, s, conf, rand_conf, B * T);
+        MM_CHECK_HIP(hipGetLastError());
+    }
     hipLaunchKernelGGL(text_commit_kernel, dim3(B), dim3(TB), (size_t)T * 8, s, conf, x0, T, ids, L, text_start, k);
     MM_CHECK_HIP(hipGetLastError());
     return 0;

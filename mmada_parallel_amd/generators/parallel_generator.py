@@ -134,8 +134,12 @@ def _ti2ti_steps(
     if not isinstance(model, LLaDAForMultiModalGeneration):
         raise TypeError("generate_ti2ti (MI355X) needs mmada_parallel_amd.LLaDAForMultiModalGeneration; "
                         "there is no PyTorch fallback path")
-    if remasking != 'low_confidence':
-        raise NotImplementedError(remasking)  # 'random' is broken in the reference with a generator
+    if remasking not in ('low_confidence', 'random'):
+        raise NotImplementedError(remasking)
+    if remasking == 'random' and generator is not None:
+        # the reference asks torch.rand for an int64 uniform on this path (:195-196) and raises
+        raise RuntimeError("remasking='random' with an explicit generator raises in the reference too "
+                           "(torch.rand(dtype=int64)); pass generator=None")
     lib, h = model._lib, model._handle
     device = model.device
     rng = rng or TorchRng()
@@ -183,7 +187,8 @@ def _ti2ti_steps(
     CBs = codebook_size
     k_cur = torch.zeros(B, dtype=torch.int32, device=device)
     mlen_cur = torch.zeros(1, dtype=torch.int32, device=device)
-    vp_text = text_temperature == 0 and model.vocab_parallel_head()  # the [B*T, V] logits are then never materialised
+    # the [B*T, V] logits are then never materialised (random re-masking ranks by a uniform draw: the one-rank kernels)
+    vp_text = text_temperature == 0 and remasking == 'low_confidence' and model.vocab_parallel_head()
     text_logits = None if vp_text else torch.empty((B * T, V), dtype=torch.bfloat16, device=device)
     cond_vq = torch.empty((B * N, CBs), dtype=torch.bfloat16, device=device) if img_steps else None
     unc = torch.empty((2 * B, L), dtype=torch.long, device=device) if need_uncond else None
@@ -218,9 +223,15 @@ def _ti2ti_steps(
             if text_temperature != 0:
                 noisy = add_gumbel_noise(text_logits.view(B, T, V), temperature=text_temperature,
                                          generator=generator, rng=rng).contiguous()
-            abi.check(lib.mmada_text_select(h, text_logits.data_ptr(), abi.ptr(noisy), B, T, V, V, ids.data_ptr(), L,
-                                            text_start, k_cur.data_ptr(), scratch.data_ptr(), st),
-                      "mmada_text_select")
+            if remasking == 'random':  # x0_p = torch.rand((B, T), device=...) (:198), drawn AFTER the Gumbel noise
+                u = (rng or TorchRng()).rand((B, T), torch.float32, device, None).contiguous()
+                abi.check(lib.mmada_text_select_random(h, text_logits.data_ptr(), abi.ptr(noisy), u.data_ptr(), B, T, V, V,
+                                                       ids.data_ptr(), L, text_start, k_cur.data_ptr(), scratch.data_ptr(),
+                                                       st), "mmada_text_select_random")
+            else:
+                abi.check(lib.mmada_text_select(h, text_logits.data_ptr(), abi.ptr(noisy), B, T, V, V, ids.data_ptr(), L,
+                                                text_start, k_cur.data_ptr(), scratch.data_ptr(), st),
+                          "mmada_text_select")
 
     def image_forwards():
         """Unconditional forwards of an image step (reference :243-274) + dual-CFG soft-max / arg-max (:282-295)."""
@@ -252,7 +263,8 @@ def _ti2ti_steps(
 
     if graph is None:
         graph = os.environ.get("MMADA_GRAPH") == "1"
-    graph = bool(graph) and temperature == 0 and text_temperature == 0 and model.graph_capturable()
+    graph = (bool(graph) and temperature == 0 and text_temperature == 0 and remasking == 'low_confidence'
+             and model.graph_capturable())  # a replayed step would replay its random draws
     graphs, seen = {}, set()
     side = torch.cuda.Stream(device=device) if graph else None
     if graph:  # the legacy default stream cannot be captured: the loop runs on a side stream, ordered after the caller's

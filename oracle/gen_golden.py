@@ -15,6 +15,7 @@ once per class, <name>.<synth.host_isa()>.npz; this script writes the file of th
   sampler_traj.npz   generate_ti2ti driven by a STUB model that returns seeded random bf16 logits: the ids the
                      sampler passes to every model call + final outputs — generators/parallel_generator.py:102-368
   paint_traj.npz     the same in painting mode: the output image span starts partly known (in- / out-painting rectangle)
+  random_traj.npz    the same with remasking='random' (uniform draws from the global CPU generator rank the text positions)
   sampler_noisy.npz  the same at temperature 1.0 / text_temperature 0.7 with every draw taken from a seeded CPU generator
   e2e_tiny.*.npz     generate_ti2ti with the real tiny model at temperature 0: ids at every model call + outputs
   dllm_cache.*.npz   LLaDAModelLM.forward(use_cache=True, to_compute_mask=..., cat=...) on the tiny model: a prime call and
@@ -203,6 +204,32 @@ def gen_paint_traj():
         n_known = int(((span != synth.MASK) & (span != synth.NEW_LINE)).sum())
         print(f"paint_traj[{name}]: {len(calls)} model calls, {n_known} of {job['seq_len']} output cells known at the start")
     np.savez_compressed(os.path.join(OUT, "paint_traj.npz"), **out)
+
+
+def gen_random_traj():
+    """generate_ti2ti with remasking='random' and generator=None (the only working form): the text positions
+    to unmask are ranked by torch.rand draws from the GLOBAL CPU generator, which mask_by_random_topk's randn also advances."""
+    from tests.helpers import RANDOM_CASES, RANDOM_SEED
+    from generators.parallel_generator import generate_ti2ti
+
+    job = tiny_job()
+    V = STUB_TEXT_VOCAB + STUB_CB
+    out = {}
+    for ci, (name, kw) in enumerate(RANDOM_CASES.items()):
+        seed = 91 + ci
+        rec = Recorder(lambda ids, call_idx, seed=seed: SimpleNamespace(
+            logits=stub_logits(seed, call_idx, ids.shape[0], ids.shape[1], V)))
+        torch.manual_seed(RANDOM_SEED)
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            vq, text = generate_ti2ti(rec, job["input_ids"], job["text_start"], job["text_end"], job["image_start"],
+                                      job["seq_len"], job["newline_every"], uncon_text=job["uncon_text"],
+                                      uncon_image=job["uncon_image"], tokenizer=None, generator=None, remasking="random",
+                                      text_vocab_size=STUB_TEXT_VOCAB, codebook_size=STUB_CB, **kw)
+        out[name + "_calls"] = torch.cat(rec.calls, 0).numpy()
+        out[name + "_text"] = np.array(text, np.int64)
+        out[name + "_seed"] = np.array(seed)
+        print(f"random_traj[{name}]: {len(rec.calls)} model calls, {len(text)} text tokens")
+    np.savez_compressed(os.path.join(OUT, "random_traj.npz"), **out)
 
 
 def gen_sampler_noisy():
@@ -662,6 +689,7 @@ if __name__ == "__main__":
     gen_m_traj()
     gen_sampler_traj()
     gen_paint_traj()
+    gen_random_traj()
     gen_sampler_noisy()
     gen_forward()
     gen_e2e()

@@ -34,7 +34,7 @@ def generate(model_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.
              cfg_scale: float, cfg_img: float, uncon_text: Optional[torch.Tensor], uncon_image: Optional[torch.Tensor],
              text_vocab_size: int = 126356, codebook_size: int = 8192, trace: Optional[list] = None,
              image_step_list: Optional[list] = None, temperature: float = 0.0, text_temperature: float = 0.0,
-             generator=None) -> torch.Tensor:
+             generator=None, remasking: str = "low_confidence") -> torch.Tensor:
     """Returns the final ids before the random fill (:360-362).  temperature / text_temperature > 0 draw from
     `generator` (a CPU generator) with the reference's calls in the reference's order: torch.rand for the text Gumbel
     noise (:13-16), torch.multinomial for the image tokens (:297-302), torch.randn for the re-mask jitter (:30-33)."""
@@ -63,7 +63,18 @@ def generate(model_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.
             if text_temperature != 0:  # add_gumbel_noise :8-20 (bf16 tensor ops)
                 u = torch.rand(tl.shape, dtype=tl.dtype, generator=generator)
                 noisy = (tl + text_temperature * (-torch.log(-torch.log(u + 1e-10) + 1e-10))).contiguous()
-            ids, _, _ = so.text_select(tl, noisy, ids, text_start, [k_sched[step]])
+            if remasking == "random":  # :194-198 with generator=None: the rank of a masked position is a uniform draw
+                assert generator is None, "the reference raises here (torch.rand with dtype=int64, SURVEY A.6b)"
+                x0 = torch.argmax(noisy if noisy is not None else tl, dim=-1)
+                u = torch.rand((x0.shape[0], x0.shape[1]))
+                masked = ids[:, text_start:text_end] == MASK_TOKEN
+                conf = torch.where(masked, u, torch.tensor(-float("inf")))
+                ids = ids.clone()
+                if k_sched[step] > 0:
+                    _, sel = torch.topk(conf[0], k=k_sched[step])  # :212
+                    ids[0, text_start + sel] = x0[0, sel]
+            else:
+                ids, _, _ = so.text_select(tl, noisy, ids, text_start, [k_sched[step]])
         if step in img_steps:  # :220
             cond_vq = cond[:, pos, lo:hi]
             ut = ui = None
@@ -88,6 +99,8 @@ def generate(model_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.
             if temperature != 0:
                 noise = torch.randn((1, seq_len), dtype=torch.bfloat16, generator=generator)  # :30-33
             else:
+                if remasking == "random":  # keep the GLOBAL generator in step: the reference draws even at temperature 0 (A.2)
+                    torch.randn((1, seq_len), dtype=torch.bfloat16)
                 noise = torch.zeros((1, seq_len), dtype=torch.bfloat16)  # temperature 0: 0 * randn
             ids = so.image_commit(ids, pos, am, pm, noise, temperature * (1.0 - ratio), mlen, MASK_TOKEN, text_vocab_size,
                                   codebook_size)

@@ -183,3 +183,11 @@ TINY_JOB_KW = dict(height=64, width=64, text_gen_length=16, prompt_len=8, uncond
 
 def paint_job(kind):
     return synth.paint_job(kind, codebook_size=STUB_CB, text_vocab=STUB_TEXT_VOCAB, **TINY_JOB_KW)
+
+
+# remasking='random' (text positions ranked by a uniform draw from the GLOBAL RNG): tests/golden/random_traj.npz
+RANDOM_CASES = {
+    "rand_img4": dict(text_steps=8, timesteps=4, cfg_scale=0.0, cfg_img=4.0, temperature=0.0, text_temperature=0.0),
+    "rand_both": dict(text_steps=9, timesteps=3, cfg_scale=2.0, cfg_img=4.0, temperature=0.0, text_temperature=0.0),
+}
+RANDOM_SEED = 4321

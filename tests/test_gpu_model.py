@@ -270,6 +270,38 @@ def test_generate_painting_mode_trajectory_bit_exact(tiny_model, name):
             assert vq[j] == int(z[name + "_vq"][j])
 
 
+@pytest.mark.parametrize("name", ["rand_img4", "rand_both"])
+def test_generate_random_remasking_trajectory_bit_exact(tiny_model, name):
+    """remasking='random': with the reference's draws replayed from the same seeded GLOBAL CPU generator (uniform ranks of
+    the text positions, the re-mask jitter's randn), every model call's ids equal the reference's recording."""
+    from helpers import RANDOM_CASES, RANDOM_SEED, ReplayCpuRng
+    from mmada_parallel_amd import generate_ti2ti
+
+    z = np.load(os.path.join(GOLDEN, "random_traj.npz"))
+    calls_ref = torch.from_numpy(z[name + "_calls"])
+    job, kw = tiny_job(), RANDOM_CASES[name]
+    V = STUB_TEXT_VOCAB + STUB_CB
+    stub = _stubbed(tiny_model, int(z[name + "_seed"]), V)
+    old = tiny_model.config.__dict__.copy()
+    torch.manual_seed(RANDOM_SEED)
+    try:
+        vq, text, final = generate_ti2ti(stub, job["input_ids"].to(DEV), job["text_start"], job["text_end"],
+                                         job["image_start"], job["seq_len"], job["newline_every"],
+                                         uncon_text=job["uncon_text"], uncon_image=job["uncon_image"], tokenizer=None,
+                                         remasking="random", text_vocab_size=STUB_TEXT_VOCAB, codebook_size=STUB_CB,
+                                         return_state=True, rng=ReplayCpuRng(), **kw)
+    finally:
+        tiny_model.config.__dict__.update(old)
+    got = torch.cat(stub.calls, 0)
+    assert got.shape == calls_ref.shape
+    assert torch.equal(got, calls_ref), f"first differing model call: {(got != calls_ref).any(1).nonzero()[0].item()}"
+    assert text == z[name + "_text"].tolist()
+    with pytest.raises(RuntimeError):  # the reference raises too with an explicit generator (torch.rand(dtype=int64))
+        generate_ti2ti(stub, job["input_ids"].to(DEV), job["text_start"], job["text_end"], job["image_start"],
+                       job["seq_len"], job["newline_every"], remasking="random", generator=torch.Generator(device=DEV),
+                       text_vocab_size=STUB_TEXT_VOCAB, codebook_size=STUB_CB, **kw)
+
+
 # --------------------------------------------------------------------------------------------- (iii) teacher-forced e2e
 def test_teacher_forced_tiny_trajectory(tiny_model):
     """Feed the reference's recorded ids of every conditional call; compare the GPU's per-position decisions

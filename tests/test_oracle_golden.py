@@ -92,6 +92,33 @@ def test_painting_mode_trajectory_matches_reference(name):
             assert tok - STUB_TEXT_VOCAB == z[name + "_vq"][j]
 
 
+@pytest.mark.parametrize("name", ["rand_img4", "rand_both"])
+def test_random_remasking_trajectory_matches_reference(name):
+    """remasking='random' (inference.py --remasking random; generators/parallel_generator.py:194-198): text positions ranked
+    by uniform draws from the global CPU generator, which the re-mask jitter's randn advances too."""
+    from helpers import RANDOM_CASES, RANDOM_SEED
+
+    z = np.load(os.path.join(GOLDEN, "random_traj.npz"))
+    job, kw = tiny_job(), RANDOM_CASES[name]
+    seed = int(z[name + "_seed"])
+    V = STUB_TEXT_VOCAB + STUB_CB
+    n = [0]
+
+    def model_fn(ids):
+        n[0] += 1
+        return stub_logits(seed, n[0], ids.shape[0], ids.shape[1], V)
+
+    trace = []
+    torch.manual_seed(RANDOM_SEED)
+    final = generate_oracle.generate(model_fn, job["input_ids"], job["text_start"], job["text_end"], job["image_start"],
+                                     job["seq_len"], job["newline_every"], uncon_text=job["uncon_text"],
+                                     uncon_image=job["uncon_image"], text_vocab_size=STUB_TEXT_VOCAB,
+                                     codebook_size=STUB_CB, trace=trace, remasking="random", **kw)
+    assert torch.equal(torch.cat(trace, 0), torch.from_numpy(z[name + "_calls"]))
+    text = [t for t in final[0, job["text_start"]:job["text_end"]].tolist() if t != synth.MASK]
+    assert text == z[name + "_text"].tolist()
+
+
 def _live_reference():
     """oracle/gen_golden.py's compute_* functions run the UNMODIFIED reference on this host; None where the reference tree
     is not mounted (GPU box)."""
