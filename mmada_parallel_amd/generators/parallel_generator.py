@@ -277,10 +277,11 @@ def _ti2ti_steps(
             with torch.cuda.stream(side) if graph else contextlib.nullcontext():
                 k_cur.copy_(k_dev[step])
                 mlen_cur.copy_(mlen_dev[step:step + 1])
-                early_noise = is_img and temperature == 0 and text_temperature == 0
+                early_noise = is_img and temperature == 0 and text_temperature == 0 and remasking == 'low_confidence'
                 if early_noise:
                     # randn is drawn even at temperature 0 (reference :30-33, A.2) so the RNG stream advances identically;
-                    # nothing else draws in a step at zero temperatures, so it can be drawn ahead of the step's launches
+                    # nothing else draws in such a step (no Gumbel noise, no random re-mask ranks), so it can be drawn
+                    # ahead of the step's launches
                     noise_buf.copy_(rng.randn((B, N), torch.bfloat16, device, generator))
                 key = (is_img, need_text)
                 if graph and key in graphs:
