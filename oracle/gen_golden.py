@@ -16,6 +16,8 @@ once per class, <name>.<synth.host_isa()>.npz; this script writes the file of th
                      sampler passes to every model call + final outputs — generators/parallel_generator.py:102-368
   paint_traj.npz     the same in painting mode: the output image span starts partly known (in- / out-painting rectangle)
   random_traj.npz    the same with remasking='random' (uniform draws from the global CPU generator rank the text positions)
+  edge_traj.npz      edge cases: CFG scales without unconditional prompts, one prompt only, complete text span, more image
+                     steps than steps, a single step
   sampler_noisy.npz  the same at temperature 1.0 / text_temperature 0.7 with every draw taken from a seeded CPU generator
   e2e_tiny.*.npz     generate_ti2ti with the real tiny model at temperature 0: ids at every model call + outputs
   dllm_cache.*.npz   LLaDAModelLM.forward(use_cache=True, to_compute_mask=..., cat=...) on the tiny model: a prime call and
@@ -230,6 +232,30 @@ def gen_random_traj():
         out[name + "_seed"] = np.array(seed)
         print(f"random_traj[{name}]: {len(rec.calls)} model calls, {len(text)} text tokens")
     np.savez_compressed(os.path.join(OUT, "random_traj.npz"), **out)
+
+
+def gen_edge_traj():
+    """Edge cases of generate_ti2ti (tests/helpers.py EDGE_CASES): CFG scales without unconditional prompts (zero logits),
+    one prompt only, a text span that is already complete, more image steps than steps, a single step."""
+    from tests.helpers import EDGE_CASES, edge_job
+
+    V = STUB_TEXT_VOCAB + STUB_CB
+    out = {}
+    for ci, name in enumerate(EDGE_CASES):
+        seed = 211 + ci
+        job, kw = edge_job(name)
+
+        def fn(ids, call_idx, seed=seed):
+            return SimpleNamespace(logits=stub_logits(seed, call_idx, ids.shape[0], ids.shape[1], V))
+
+        calls, vq, text = run_reference_sampler(fn, job, temperature=0.0, text_temperature=0.0,
+                                                text_vocab_size=STUB_TEXT_VOCAB, codebook_size=STUB_CB, **kw)
+        out[name + "_calls"] = torch.cat(calls, 0).numpy()
+        out[name + "_vq"] = np.array(vq, np.int64)
+        out[name + "_text"] = np.array(text, np.int64)
+        out[name + "_seed"] = np.array(seed)
+        print(f"edge_traj[{name}]: {len(calls)} model calls, {len(text)} text tokens")
+    np.savez_compressed(os.path.join(OUT, "edge_traj.npz"), **out)
 
 
 def gen_sampler_noisy():
@@ -690,6 +716,7 @@ if __name__ == "__main__":
     gen_sampler_traj()
     gen_paint_traj()
     gen_random_traj()
+    gen_edge_traj()
     gen_sampler_noisy()
     gen_forward()
     gen_e2e()

@@ -191,3 +191,33 @@ RANDOM_CASES = {
     "rand_both": dict(text_steps=9, timesteps=3, cfg_scale=2.0, cfg_img=4.0, temperature=0.0, text_temperature=0.0),
 }
 RANDOM_SEED = 4321
+
+
+# edge cases of generate_ti2ti (tests/golden/edge_traj.npz): name -> (job tweak, uncon_text given, uncon_image given, kwargs)
+EDGE_CASES = {
+    # CFG scales > 0 but no unconditional prompts: the reference substitutes ZERO logits for both branches (:275-278)
+    "cfg_without_uncond": ("plain", False, False, dict(text_steps=6, timesteps=3, cfg_scale=1.5, cfg_img=4.0)),
+    # only the image branch has an unconditional prompt: both forwards still run (:243), the text one on the plain ids
+    "only_uncon_image": ("plain", False, True, dict(text_steps=6, timesteps=3, cfg_scale=2.0, cfg_img=3.0)),
+    # the text span is already complete: no text step ever runs (:183), image steps still do
+    "text_done": ("text_done", True, True, dict(text_steps=5, timesteps=5, cfg_scale=0.0, cfg_img=4.0)),
+    # more image steps requested than steps exist: linspace repeats indices, `step in list` runs each once
+    "more_timesteps_than_steps": ("plain", True, True, dict(text_steps=4, timesteps=9, cfg_scale=0.0, cfg_img=4.0)),
+    # a single step: the image step coincides with the only text step, ratio = 1 -> one cell left masked
+    "single_step": ("plain", True, True, dict(text_steps=1, timesteps=1, cfg_scale=0.0, cfg_img=4.0)),
+}
+
+
+def edge_job(name):
+    tweak, ut, ui, kw = EDGE_CASES[name]
+    job = tiny_job()
+    if tweak == "text_done":
+        g = torch.Generator().manual_seed(77)
+        ids = job["input_ids"].clone()
+        ids[0, job["text_start"]:job["text_end"]] = torch.randint(0, 1000, (job["text_end"] - job["text_start"],), generator=g)
+        job["input_ids"] = ids
+    if not ut:
+        job["uncon_text"] = None
+    if not ui:
+        job["uncon_image"] = None
+    return job, kw

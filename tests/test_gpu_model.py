@@ -302,6 +302,39 @@ def test_generate_random_remasking_trajectory_bit_exact(tiny_model, name):
                        text_vocab_size=STUB_TEXT_VOCAB, codebook_size=STUB_CB, **kw)
 
 
+@pytest.mark.parametrize("name", ["cfg_without_uncond", "only_uncon_image", "text_done", "more_timesteps_than_steps", "single_step"])
+def test_generate_edge_case_trajectory_bit_exact(tiny_model, name):
+    """Edge cases of the loop (tests/helpers.py EDGE_CASES) against the reference's recordings: CFG scales without
+    unconditional prompts (zero logits stand in), one prompt only, a complete text span, more image steps than steps, a
+    single step."""
+    from helpers import edge_job
+    from mmada_parallel_amd import generate_ti2ti
+
+    z = np.load(os.path.join(GOLDEN, "edge_traj.npz"))
+    calls_ref = torch.from_numpy(z[name + "_calls"])
+    job, kw = edge_job(name)
+    V = STUB_TEXT_VOCAB + STUB_CB
+    stub = _stubbed(tiny_model, int(z[name + "_seed"]), V)
+    old = tiny_model.config.__dict__.copy()
+    try:
+        vq, text, final = generate_ti2ti(stub, job["input_ids"].to(DEV), job["text_start"], job["text_end"],
+                                         job["image_start"], job["seq_len"], job["newline_every"], temperature=0.0,
+                                         text_temperature=0.0, uncon_text=job["uncon_text"], uncon_image=job["uncon_image"],
+                                         tokenizer=None, text_vocab_size=STUB_TEXT_VOCAB, codebook_size=STUB_CB,
+                                         return_state=True, **kw)
+    finally:
+        tiny_model.config.__dict__.update(old)
+    got = torch.cat(stub.calls, 0)
+    assert got.shape == calls_ref.shape, f"{got.shape[0]} model calls, the reference made {calls_ref.shape[0]}"
+    assert torch.equal(got, calls_ref), f"first differing model call: {(got != calls_ref).any(1).nonzero()[0].item()}"
+    assert text == z[name + "_text"].tolist()
+    pos = [i for i in range(job["image_start"], job["image_start"] + job["seq_len"] + job["seq_len"] // job["newline_every"])
+           if int(job["input_ids"][0, i]) != synth.NEW_LINE]
+    for j, p in enumerate(pos):
+        if int(final[0, p]) != synth.MASK:
+            assert vq[j] == int(z[name + "_vq"][j])
+
+
 # --------------------------------------------------------------------------------------------- (iii) teacher-forced e2e
 def test_teacher_forced_tiny_trajectory(tiny_model):
     """Feed the reference's recorded ids of every conditional call; compare the GPU's per-position decisions

@@ -119,6 +119,32 @@ def test_random_remasking_trajectory_matches_reference(name):
     assert text == z[name + "_text"].tolist()
 
 
+@pytest.mark.parametrize("name", ["cfg_without_uncond", "only_uncon_image", "text_done", "more_timesteps_than_steps", "single_step"])
+def test_edge_case_trajectory_matches_reference(name):
+    from helpers import edge_job
+
+    z = np.load(os.path.join(GOLDEN, "edge_traj.npz"))
+    job, kw = edge_job(name)
+    seed = int(z[name + "_seed"])
+    V = STUB_TEXT_VOCAB + STUB_CB
+    n = [0]
+
+    def model_fn(ids):
+        n[0] += 1
+        return stub_logits(seed, n[0], ids.shape[0], ids.shape[1], V)
+
+    trace = []
+    final = generate_oracle.generate(model_fn, job["input_ids"], job["text_start"], job["text_end"], job["image_start"],
+                                     job["seq_len"], job["newline_every"], uncon_text=job["uncon_text"],
+                                     uncon_image=job["uncon_image"], text_vocab_size=STUB_TEXT_VOCAB,
+                                     codebook_size=STUB_CB, trace=trace, **kw)
+    got = torch.cat(trace, 0)
+    ref = torch.from_numpy(z[name + "_calls"])
+    assert got.shape == ref.shape and torch.equal(got, ref)
+    text = [t for t in final[0, job["text_start"]:job["text_end"]].tolist() if t != synth.MASK]
+    assert text == z[name + "_text"].tolist()
+
+
 def _live_reference():
     """oracle/gen_golden.py's compute_* functions run the UNMODIFIED reference on this host; None where the reference tree
     is not mounted (GPU box)."""
