@@ -18,6 +18,8 @@ once per class, <name>.<synth.host_isa()>.npz; this script writes the file of th
   random_traj.npz    the same with remasking='random' (uniform draws from the global CPU generator rank the text positions)
   edge_traj.npz      edge cases: CFG scales without unconditional prompts, one prompt only, complete text span, more image
                      steps than steps, a single step
+  image_utils_tokens.npz  the reference's encode_img_with_breaks / encode_img_with_paint (utils/image_utils.py:159-284) on a
+                     fake tokenizer, imported with a stub `diffusers`
   sampler_noisy.npz  the same at temperature 1.0 / text_temperature 0.7 with every draw taken from a seeded CPU generator
   e2e_tiny.*.npz     generate_ti2ti with the real tiny model at temperature 0: ids at every model call + outputs
   dllm_cache.*.npz   LLaDAModelLM.forward(use_cache=True, to_compute_mask=..., cat=...) on the tiny model: a prime call and
@@ -256,6 +258,59 @@ def gen_edge_traj():
         out[name + "_seed"] = np.array(seed)
         print(f"edge_traj[{name}]: {len(calls)} model calls, {len(text)} text tokens")
     np.savez_compressed(os.path.join(OUT, "edge_traj.npz"), **out)
+
+
+def gen_image_utils():
+    """The reference's own utils/image_utils.py functions around the tokenizer.  The module imports `diffusers` at the top
+    (VQModel, VaeImageProcessor), which is not installed: a stub module supplies them — VQModel is only a type annotation
+    there, and VaeImageProcessor(vae_scale_factor, do_normalize=False).preprocess is the PIL + numpy restatement of
+    mmada_parallel_amd/utils/image_utils.py (the one thing this fixture cannot pin).  Everything else — token layout, special
+    ids, the in- / out-painting mask geometry, dilation, the three mask down-samplers — is the reference's code."""
+    import types
+
+    from PIL import Image
+
+    from mmada_parallel_amd.utils import image_utils as mine
+    from tests.helpers import PAINT_UTIL_CASES, FakeVq, paint_util_image
+
+    class VaeImageProcessor:
+        def __init__(self, vae_scale_factor=8, do_normalize=True, **_):
+            assert not do_normalize
+            self.f = vae_scale_factor
+
+        def preprocess(self, img):
+            return mine.pil_to_unit_tensor(img, self.f)
+
+        def postprocess(self, x, output_type="pil"):
+            return mine.unit_tensor_to_pil(x)
+
+    stub = types.ModuleType("diffusers")
+    stub.VQModel = object
+    sub = types.ModuleType("diffusers.image_processor")
+    sub.VaeImageProcessor = VaeImageProcessor
+    stub.image_processor = sub
+    saved = {k: sys.modules.get(k) for k in ("diffusers", "diffusers.image_processor", "utils", "utils.image_utils")}
+    sys.modules["diffusers"], sys.modules["diffusers.image_processor"] = stub, sub
+    for k in ("utils", "utils.image_utils"):
+        sys.modules.pop(k, None)
+    try:
+        import importlib
+
+        ref = importlib.import_module("utils.image_utils")
+        img, vq = Image.fromarray(paint_util_image()), FakeVq()
+        out = {"breaks": np.array(ref.encode_img_with_breaks(img, vq, vae_scale_factor=2), np.int64)}
+        for name, kw in PAINT_UTIL_CASES.items():
+            toks, vis = ref.encode_img_with_paint(img, vq, **kw)
+            out[name + "_tokens"] = np.array(toks, np.int64)
+            out[name + "_vis"] = np.asarray(vis)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    np.savez_compressed(os.path.join(OUT, "image_utils_tokens.npz"), **out)
+    print("image_utils_tokens:", {k: v.shape for k, v in out.items() if k.endswith("_tokens") or k == "breaks"})
 
 
 def gen_sampler_noisy():
@@ -717,6 +772,7 @@ if __name__ == "__main__":
     gen_paint_traj()
     gen_random_traj()
     gen_edge_traj()
+    gen_image_utils()
     gen_sampler_noisy()
     gen_forward()
     gen_e2e()

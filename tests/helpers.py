@@ -221,3 +221,37 @@ def edge_job(name):
     if not ui:
         job["uncon_image"] = None
     return job, kw
+
+
+class FakeVq:
+    """CPU stand-in with the surface utils/image_utils.py touches: latents = 2x2 mean of the red channel, index = its
+    value quantised to 0..63 (so token arithmetic and mask geometry can be checked without a GPU)."""
+
+    def __init__(self):
+        from types import SimpleNamespace
+
+        self.config = SimpleNamespace(block_out_channels=[1, 1], latent_channels=1)
+        self.device = torch.device("cpu")
+
+    def encode(self, x):
+        from types import SimpleNamespace
+
+        return SimpleNamespace(latents=torch.nn.functional.avg_pool2d(x[:, :1], 2))
+
+    def quantize(self, latents):
+        return None, None, (None, None, (latents.reshape(-1) * 63).round().long())
+
+
+# utils/image_utils.py against the reference's own functions (tests/golden/image_utils_tokens.npz)
+PAINT_UTIL_CASES = {
+    "inpaint": dict(mask_h_ratio=0.5, mask_w_ratio=0.25, mask_mode="inpainting"),
+    "outpaint": dict(mask_h_ratio=0.5, mask_w_ratio=0.25, mask_mode="outpainting"),
+    "inpaint_dilated": dict(mask_h_ratio=0.4, mask_w_ratio=0.3, dilate_latent_k=1, mask_mode="inpainting"),
+    "inpaint_nearest": dict(mask_h_ratio=0.37, mask_w_ratio=0.21, downsample_mode="nearest", mask_mode="inpainting"),
+    "outpaint_bilinear": dict(mask_h_ratio=0.55, mask_w_ratio=0.45, downsample_mode="bilinear", gray_value=90, mask_mode="outpainting"),
+}
+
+
+def paint_util_image():
+    rng = np.random.default_rng(5)
+    return rng.integers(0, 256, size=(36, 70, 3), dtype=np.uint8)       # resized to 36 x 70 -> multiples of 2: unchanged size

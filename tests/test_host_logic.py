@@ -1,6 +1,7 @@
 """Host-side logic (no GPU): schedules, sequence layout, prompt templates — checked against the reference's own
 formulas (generators/parallel_generator.py:73-99,157-159,318-321; inference.py:117-161; SURVEY.md §8d numbers)."""
 import math
+import os
 
 import torch
 
@@ -125,3 +126,59 @@ def test_image_processor_restatement_round_trip():
     assert y.shape == (1, 3, 32, 64) and 0.0 <= float(y.min()) <= float(y.max()) <= 1.0
     toks = iu.add_break_line(list(range(6)), 2, 3, new_number=126084)
     assert toks == [0, 1, 2, 126084, 3, 4, 5, 126084]
+
+
+def test_paint_and_break_token_layout_on_a_fake_tokenizer():
+    """encode_img_with_breaks / encode_img_with_paint (reference utils/image_utils.py:159-173,175-284): special tokens, row
+    breaks, VQ offset, and which latent cells an in- / out-painting rectangle masks (area down-sampling, > 0.5)."""
+    import numpy as np
+    from PIL import Image
+
+    from mmada_parallel_amd.utils import image_utils as iu
+
+    rng = np.random.default_rng(1)
+    arr = rng.integers(0, 256, size=(32, 64, 3), dtype=np.uint8)          # H = 32, W = 64 -> 16 x 32 latent cells
+    from helpers import FakeVq
+
+    img, vq = Image.fromarray(arr), FakeVq()
+    toks = iu.encode_img_with_breaks(img, vq, vae_scale_factor=2)
+    assert toks[0] == 126349 and toks[-1] == 126350 and len(toks) == 2 + 16 * 33
+    body = toks[1:-1]
+    assert all(body[r * 33 + 32] == 126084 for r in range(16))
+    x = torch.from_numpy(arr.astype(np.float32) / 255.0).permute(2, 0, 1)[None]
+    want = (torch.nn.functional.avg_pool2d(x[:, :1], 2).reshape(-1) * 63).round().long() + 126356
+    assert [t for i, t in enumerate(body) if i % 33 != 32] == want.tolist()
+    # rectangle of half the height and a quarter of the width, centred: pixel rows 8..23, columns 24..39 -> cells 4..11 x 12..19
+    inp, vis = iu.encode_img_with_paint(img, vq, mask_h_ratio=0.5, mask_w_ratio=0.25, mask_mode="inpainting")
+    out, _ = iu.encode_img_with_paint(img, vq, mask_h_ratio=0.5, mask_w_ratio=0.25, mask_mode="outpainting")
+    assert vis.size == (64, 32) and len(inp) == len(out) == 16 * 33
+    grid_in = torch.tensor([t for i, t in enumerate(inp) if i % 33 != 32]).view(16, 32)
+    grid_out = torch.tensor([t for i, t in enumerate(out) if i % 33 != 32]).view(16, 32)
+    inside = torch.zeros(16, 32, dtype=torch.bool)
+    inside[4:12, 12:20] = True
+    assert torch.equal(grid_in == 126336, inside) and torch.equal(grid_out == 126336, ~inside)
+    assert torch.equal(grid_in[~inside], want.view(16, 32)[~inside]) and torch.equal(grid_out[inside], want.view(16, 32)[inside])
+    assert np.asarray(vis)[16, 32].tolist() == [127, 127, 127] and np.asarray(vis)[0, 0].tolist() == arr[0, 0].tolist()
+    # one cell of dilation grows the masked block by a ring
+    dil, _ = iu.encode_img_with_paint(img, vq, mask_h_ratio=0.5, mask_w_ratio=0.25, dilate_latent_k=1)
+    grid_d = torch.tensor([t for i, t in enumerate(dil) if i % 33 != 32]).view(16, 32)
+    assert int((grid_d == 126336).sum()) == 10 * 10
+
+
+def test_pixel_token_helpers_match_the_reference_functions():
+    """tests/golden/image_utils_tokens.npz: the reference's own encode_img_with_breaks / encode_img_with_paint (imported with
+    a stub `diffusers` whose VaeImageProcessor is the restatement in utils/image_utils.py) on a fake tokenizer and a seeded
+    image — token layout, special ids, mask geometry for both modes, dilation and the nearest / bilinear mask samplers."""
+    import numpy as np
+    from PIL import Image
+
+    from helpers import GOLDEN, FakeVq, PAINT_UTIL_CASES, paint_util_image
+    from mmada_parallel_amd.utils import image_utils as iu
+
+    z = np.load(os.path.join(GOLDEN, "image_utils_tokens.npz"))
+    img, vq = Image.fromarray(paint_util_image()), FakeVq()
+    assert iu.encode_img_with_breaks(img, vq, vae_scale_factor=2) == z["breaks"].tolist()
+    for name, kw in PAINT_UTIL_CASES.items():
+        toks, vis = iu.encode_img_with_paint(img, vq, **kw)
+        assert toks == z[name + "_tokens"].tolist(), name
+        assert np.array_equal(np.asarray(vis), z[name + "_vis"]), name
