@@ -303,6 +303,8 @@ def gen_image_utils():
             toks, vis = ref.encode_img_with_paint(img, vq, **kw)
             out[name + "_tokens"] = np.array(toks, np.int64)
             out[name + "_vis"] = np.asarray(vis)
+        codes = torch.arange(18 * 35).view(1, -1) % 64
+        out["decoded"] = np.asarray(ref.decode_vq_to_image(codes, None, None, 36, 70, vq))
     finally:
         for k, v in saved.items():
             if v is None:

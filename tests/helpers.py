@@ -241,6 +241,14 @@ class FakeVq:
     def quantize(self, latents):
         return None, None, (None, None, (latents.reshape(-1) * 63).round().long())
 
+    def decode(self, codes, force_not_quantize=False, shape=None):
+        from types import SimpleNamespace
+
+        assert force_not_quantize and tuple(shape) == (codes.shape[0], codes.shape[1], codes.shape[2], 1)
+        g = codes.float() / 63.0 * 1.2 - 0.1                               # leaves [0, 1] on both sides: the clip matters
+        x = torch.stack([g, 1.0 - g, g * g], 1)
+        return SimpleNamespace(sample=torch.nn.functional.interpolate(x, scale_factor=2.0, mode="nearest"))
+
 
 # utils/image_utils.py against the reference's own functions (tests/golden/image_utils_tokens.npz)
 PAINT_UTIL_CASES = {

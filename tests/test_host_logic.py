@@ -182,3 +182,9 @@ def test_pixel_token_helpers_match_the_reference_functions():
         toks, vis = iu.encode_img_with_paint(img, vq, **kw)
         assert toks == z[name + "_tokens"].tolist(), name
         assert np.array_equal(np.asarray(vis), z[name + "_vis"]), name
+    codes = torch.arange(18 * 35).view(1, -1) % 64
+    assert np.array_equal(np.asarray(iu.decode_vq_to_image(codes, None, None, 36, 70, vq)), z["decoded"])
+    import pytest
+
+    with pytest.raises(ValueError):
+        iu.decode_vq_to_image(codes[:, :-1], None, None, 36, 70, vq)
