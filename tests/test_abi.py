@@ -34,6 +34,34 @@ def test_argument_errors_are_reported_without_a_gpu():
     assert lib.mmada_workspace_bytes(None, 1, 16) == 0
 
 
+def test_new_entry_points_reject_bad_arguments_without_a_gpu():
+    """dLLM cache, random re-masking and the A tokenizer entry points validate before they touch the device."""
+    import ctypes as C
+
+    from mmada_parallel_amd.vqmodel import VqModelCfg
+
+    lib = abi.lib()
+    assert lib.mmada_cache_bytes(None, 1, 16) == 0
+    assert lib.mmada_cache_bind(None, 0, None, 0, 1, 16, None) != 0 and b"null" in lib.mmada_last_error()
+    assert lib.mmada_forward_cached(None, 0, None, None, 1, 16, 16, 1, None) != 0
+    assert lib.mmada_cache_head_rows(None, 0, None, 1, 0, 8, None, None) != 0
+    assert lib.mmada_text_select_random(None, None, None, None, 1, 4, 64, 64, None, 8, 0, None, None, None) != 0
+    assert lib.mmada_vq_nearest_code(None, None, 4, None, None) != 0
+    h = C.c_void_p()
+    c = VqModelCfg()
+    c.n_levels, c.layers_per_block, c.latent_channels, c.vq_embed_dim = 2, 1, 8, 8
+    c.num_vq_embeddings, c.image_channels, c.mid_block_add_attention, c.norm_num_groups = 64, 3, 1, 32
+    c.block_out_channels[0], c.block_out_channels[1] = 128, 200          # not a multiple of 128
+    assert lib.mmada_vq_create_vqmodel(C.byref(c), 0, C.byref(h)) != 0 and b"multiple of 128" in lib.mmada_last_error()
+    c.block_out_channels[1] = 256
+    c.norm_num_groups = 16
+    assert lib.mmada_vq_create_vqmodel(C.byref(c), 0, C.byref(h)) != 0 and b"norm_num_groups" in lib.mmada_last_error()
+    c.norm_num_groups = 32
+    assert lib.mmada_vq_create_vqmodel(C.byref(c), 1, C.byref(h)) == 0    # building the graph needs no device
+    assert lib.mmada_vq_num_unbound(h) > 0
+    lib.mmada_vq_destroy(h)
+
+
 def test_product_path_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "mmada_parallel_amd")
     for dirpath, _, files in os.walk(pkg):
