@@ -160,7 +160,8 @@ class VQModel:
         abi.check(self._lib.mmada_vq_get_code(self._enc, x.data_ptr(), B, H, W, ws, nb, idx.data_ptr(), z.data_ptr(),
                                               abi.stream_ptr()), "mmada_vq_get_code")
         latents = z.view(B, hz, wz, D).permute(0, 3, 1, 2).contiguous()
-        self._last = (latents, idx)  # quantize(latents) on this very tensor reuses the indices computed alongside
+        # quantize(latents) on this very (unmodified) tensor reuses the indices computed alongside
+        self._last = (latents, idx, latents._version)
         return SimpleNamespace(latents=latents) if return_dict else (latents,)
 
     def quantize(self, latents: torch.Tensor):
@@ -168,7 +169,7 @@ class VQModel:
         [2][2] (utils/image_utils.py:168).  Indices are flat [B*h*w] like diffusers' (sane_index_shape=False)."""
         last = getattr(self, "_last", None)
         B, D, hz, wz = latents.shape
-        if last is not None and last[0] is latents:
+        if last is not None and last[0] is latents and latents._version == last[2]:
             idx = last[1].reshape(-1)
         else:
             z = latents.to(device=self.device, dtype=torch.float32).permute(0, 2, 3, 1).contiguous()

@@ -64,6 +64,9 @@ def test_tiny_vqmodel_decode_encode_quantize_vs_oracle():
     # quantize() on latents that did not come from encode(): the stand-alone nearest-code entry point, same answer
     idx2 = vq.quantize(lat.clone())[2][2]
     assert torch.equal(idx2, idx)
+    lat.mul_(-1.0)                                  # modified in place after encode(): the cached indices must not be reused
+    assert torch.equal(vq.quantize(lat)[2][2], vq.quantize(lat.clone())[2][2]) and not torch.equal(vq.quantize(lat)[2][2], idx)
+    lat.mul_(-1.0)
     # float latents through decode(): quantised first, like diffusers without force_not_quantize
     rec = vq.decode(lat).sample
     assert torch.equal(rec, vq.decode(idx.view(2, 16, 16), force_not_quantize=True).sample)
