@@ -476,7 +476,13 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, **wl["cpu"])
-        print(json.dumps(out))
+        # native libraries (RCCL's version banner, gloo's connection notes) write to the C stdio buffer of fd 1, which is
+        # only flushed at exit when stdout is a pipe: push that out first so that the JSON line is the LAST line of stdout
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
 
