@@ -1132,7 +1132,10 @@ int launch_var(const GemmArgs& g, hipStream_t s) {
 
 }  // namespace
 
+int launch_gemm8_variant(int variant, const GemmArgs& g, hipStream_t s);  // gemm8.hip
+
 int launch_gemm_variant(int variant, const GemmArgs& g, hipStream_t s) {
+    if (variant >= 200 && variant < 300) return launch_gemm8_variant(variant, g, s);
     if (g.K % 64) return mm_fail("gemm_variant: K must be a multiple of 64");
     switch (variant) {
         case 100: return launch_gemm(EPI_STORE, g, s);  // the production kernel (BM picker included)
