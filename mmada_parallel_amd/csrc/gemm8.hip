@@ -1,0 +1,311 @@
+// gemm8.hip — the 8-phase bf16 MFMA GEMM  C[M,N] = A[M,K] · W[N,K]^T  for gfx950 (round 3; same contraction, same fused
+// epilogues and the same K order — hence bit-identical results — as the 16-wave kernel of gemm.hip, 12-21 % faster on the
+// projection shapes of the 8B block: profiles/r03_gemm8_sweep*.txt).
+//
+// It replaces F.linear in q/k/v_proj, attn_out, ff_proj/up_proj, ff_out (model/modeling_llada.py:925-927, 741-744, 962-970).
+//
+// Structure (CDNA guide §5 "256² 8-phase template", T3 + T4, rebuilt for several tile shapes):
+//   * BM x BN x 64 tile, 8 waves = WM x WN, TWO waves per SIMD (256 registers each); a wave owns TM x TN outputs.
+//   * a K-tile is FOUR phases; a phase multiplies one quadrant of the wave tile: one A half (FA fragments x 2 k-steps, held
+//     in registers for two phases) against one W half (FB fragments x 2 k-steps):
+//         P1 (A0,B0)   P2 (A0,B1)   P3 (A1,B1)   P4 (A1,B0)
+//     phase = { LDS-DMA issue for a later K-tile ; ds_read_b128 of the operand half that changes ; counted vmcnt ; barrier ;
+//               MFMA cluster ; barrier }.
+//   * the LDS image of a K-tile is cut the same way into four HALF-TILES (A0, A1, B0, B1 = the rows every wave reads for
+//     that half).  A half-tile slot is re-filled two phases after its last ds_read, with the data of the K-tile AFTER next:
+//     four half-tiles (one whole K-tile, up to 72 KiB per CU) are always in flight, each issued at least four phases — one
+//     K-tile of MFMA time — before it is needed, and the queue never drains: every wait is a COUNTED vmcnt that leaves four
+//     half-tiles outstanding.  (The 16-wave kernel requests K-tile t+1 in one burst behind the barrier of K-tile t and
+//     drains the queue at the next barrier: 41 % of its wave time was spent there, profiles/r02_pmc_sq_model.txt.)
+//   * the two wave groups (waves 0-3 / 4-7: one of each on every SIMD) run ONE BARRIER APART: while one wave of a SIMD is
+//     in its MFMA cluster its partner issues the ds_reads and LDS-DMA of its next phase (measured: -18 % without it).
+// Hazard rules (guide: "read a staged buffer one phase AFTER the wait that retires it" / WAR two phases), checked for
+// every K-tile count by tests/test_host_logic.py::test_gemm8_schedule (a program-order simulation of the queue):
+//   RAW: a half-tile is read in the phase after the one whose (pre-barrier) counted wait retired it;
+//   WAR: a slot is re-staged >= 2 phases after the phase that read it.
+// The counted waits assume that NOTHING but LDS-DMA is in the vector-memory queue between the prologue and the last
+// wait: tests/test_isa.py disassembles the library and checks that the main loops contain no scratch or global access.
+#include <cstdlib>
+
+#include "gemm_epilogue.h"
+
+namespace {
+
+using namespace gemm_detail;
+
+constexpr int BK = 64;
+
+#define G8_SB() __builtin_amdgcn_sched_barrier(0)
+#define G8_BARRIER()                            \
+    do {                                        \
+        G8_SB();                                \
+        asm volatile("s_barrier" ::: "memory"); \
+        G8_SB();                                \
+    } while (0)
+
+// The kernel owns the whole LDS allocation and has no static __shared__ object, so the dynamic segment starts at LDS
+// address 0 (tests/test_isa.py: group_segment_fixed_size == 0): LDS addresses are formed from plain integers, which
+// spares the "base + offset" VALU add and its temporary per access (the 320-row tile has 24 registers to spare).
+typedef __attribute__((address_space(3))) const bf16x8* lds_frag_ptr;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+#pragma clang diagnostic ignored "-Wint-to-void-pointer-cast"
+MM_DEVICE lds_frag_ptr lds_frag(int byte_off) { return (lds_frag_ptr)(uint32_t)byte_off; }
+MM_DEVICE lptr_t lds_at(int byte_off) { return (lptr_t)(uint32_t)byte_off; }
+#pragma clang diagnostic pop
+
+template <int N>
+MM_DEVICE void wait_vm() {
+    G8_SB();
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    G8_SB();
+}
+
+template <int BM_, int BN_, int WM_, int WN_>
+struct Gemm8 {
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
+    static constexpr int FA0 = (FM + 1) / 2, FA1 = FM / 2, FB = FN / 2;  // fragments of the A halves / of a W half
+    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES, LDS = 2 * STAGE;
+    // 1-KiB LDS-DMA pieces (8 rows x 128 B) per half-tile; wave w moves pieces w, w+8, w+16
+    static constexpr int NPA0 = WM * FA0 * 2, NPA1 = WM * FA1 * 2, NPB = WN * FB * 2;
+    static constexpr int RA0 = NPA0 % 8, RA1 = NPA1 % 8;  // waves below the remainder move one piece more
+    static constexpr int REM = RA0 ? RA0 : RA1;           // the one wave-uniform predicate that separates the two code paths
+    static constexpr int NB = NPB / 8;
+    static_assert(WM * WN == 8 && TM % 16 == 0 && TN % 32 == 0 && FA1 >= 1, "wave tile");
+    static_assert(NPB % 8 == 0 && (RA0 == 0 || RA1 == 0 || RA0 == RA1) && NPA0 <= 24 && NPA1 <= 24, "piece split");
+    static_assert(LDS <= 160 * 1024, "LDS");
+
+    const char* Ab;  // wave-uniform byte bases of the A / W panels of this output tile
+    const char* Wb;
+    const char* Zb;  // 8 zero rows of lda elements (source of A pieces that lie wholly beyond M), or null
+    // LDS-DMA addressing: a piece's first row is wave-uniform and goes into the SCALAR base; the per-lane part (row inside
+    // the piece, swizzled 16-B chunk) is ONE 32-bit register per operand: the swizzle of row r is (r >> 1) & 7 and a piece
+    // starts at a multiple of 8 rows, so the lane part depends on the piece's parity only — which is the wave's parity
+    // (a wave's pieces are 8 apart and every chunk of a half-tile holds an even number of pieces).
+    unsigned alane, wlane;
+    unsigned arow[2][3], wrow[2][2];  // wave-uniform source byte offsets of this wave's pieces, [half][piece]
+    bool azero[2][3];                 // piece lies wholly beyond M: stream zeros (the products are discarded either way,
+                                      // but MFMAs on zeros switch far less — this workload runs at the power limit)
+    int alds[2][3], wlds[2][2];       // wave-uniform LDS byte offsets of those pieces inside a stage
+    int ra[2][2], rb[2][2];           // per-lane LDS read offsets [buffer][k-step] of fragment 0 (the rest are immediates;
+                                      // the second buffer's offsets exceed the 16-bit immediate range)
+    bf16x8 af[FA0][2], bf0[FB][2], bf1[FB][2];
+    f32x4 acc[FM][FN];
+
+    MM_DEVICE void init(const GemmArgs& g, int m0, int n0, int wave, int lane) {
+        Ab = (const char*)(g.A + (size_t)m0 * g.lda);
+        Wb = (const char*)(g.W + (size_t)n0 * g.ldw);
+        Zb = (const char*)g.zero_row;
+        const int wm = wave / WN, wn = wave % WN;
+        const int prow = lane >> 3, psw = ((wave & 1) * 4 + (prow >> 1)) & 7;
+        alane = (unsigned)prow * (unsigned)(g.lda * 2) + (((lane & 7) ^ psw) << 4);
+        wlane = (unsigned)prow * (unsigned)(g.ldw * 2) + (((lane & 7) ^ psw) << 4);
+        const int mrem = g.M - m0, nrem = g.N - n0;  // rows of this tile that exist (multiples of 8: gemm8_supports)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int fa = h ? FA1 : FA0, npa = h ? NPA1 : NPA0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int p = min(wave + 8 * i, npa - 1);
+                const int row0 = (p / (fa * 2)) * TM + (h ? FA0 * 16 : 0) + (p % (fa * 2)) * 8;
+                azero[h][i] = Zb != nullptr && row0 >= mrem;
+                arow[h][i] = azero[h][i] ? 0u : (unsigned)min(row0, mrem - 8) * (unsigned)(g.lda * 2);
+                alds[h][i] = row0 * 128;
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i) {
+                const int p = wave + 8 * i;
+                const int row0 = (p / (FB * 2)) * TN + h * FB * 16 + (p % (FB * 2)) * 8;
+                wrow[h][i] = (unsigned)min(row0, nrem - 8) * (unsigned)(g.ldw * 2);
+                wlds[h][i] = A_BYTES + row0 * 128;
+            }
+        }
+        const int frow = lane & 15, fq = lane >> 4, sw = (frow >> 1) & 7;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const int lanepart = frow * 128 + (((kk * 4 + fq) ^ sw) << 4);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                ra[b][kk] = b * STAGE + wm * TM * 128 + lanepart;
+                rb[b][kk] = b * STAGE + A_BYTES + wn * TN * 128 + lanepart;
+                asm volatile("" : "+v"(ra[b][kk]), "+v"(rb[b][kk]));  // opaque: four bases per operand, never re-derived
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    template <int B, int H, int NA>
+    MM_DEVICE void stage_a(int kt) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const char* src = (azero[H][i] ? Zb : Ab + arow[H][i]) + (size_t)kt * (BK * 2);
+            unsigned off = alane;
+            asm volatile("" : "+s"(src), "+v"(off));  // scalar base + 32-bit lane offset, zero-extended HERE: saddr form
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + off), lds_at(B * STAGE + alds[H][i]), 16, 0, 0);
+        }
+    }
+    template <int B, int H>
+    MM_DEVICE void stage_w(int kt) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const char* src = Wb + wrow[H][i] + (size_t)kt * (BK * 2);
+            unsigned off = wlane;
+            asm volatile("" : "+s"(src), "+v"(off));
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + off), lds_at(B * STAGE + wlds[H][i]), 16, 0, 0);
+        }
+    }
+    template <int B, int H>
+    MM_DEVICE void read_a() {
+#pragma unroll
+        for (int mi = 0; mi < (H ? FA1 : FA0); ++mi)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) af[mi][kk] = *lds_frag(ra[B][kk] + ((H ? FA0 * 16 : 0) + mi * 16) * 128);
+    }
+    template <int B, int H>
+    MM_DEVICE void read_b(bf16x8 (&bf)[FB][2]) {
+#pragma unroll
+        for (int nj = 0; nj < FB; ++nj)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) bf[nj][kk] = *lds_frag(rb[B][kk] + (H * FB * 16 + nj * 16) * 128);
+    }
+    template <int H, int NH>
+    MM_DEVICE void mma(bf16x8 (&bf)[FB][2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int mi = 0; mi < (H ? FA1 : FA0); ++mi)
+#pragma unroll
+                for (int nj = 0; nj < FB; ++nj) {
+                    f32x4& c = acc[(H ? FA0 : 0) + mi][NH * FB + nj];
+                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][kk], bf[nj][kk], c, 0, 0, 0);
+                }
+    }
+
+    // One K-tile (index kt, LDS buffer B).  TAIL 0: steady state (kt + 2 < nk); 1: second-to-last; 2: last K-tile.
+    // LDS-DMA queue, oldest first, at the top of P1(kt): B1(kt) A1(kt) A0(kt+1) B0(kt+1)  (A0, B0 of kt have landed).
+    template <int B, int NA0, int NA1, int TAIL>
+    MM_DEVICE void tile(int kt) {
+        constexpr int FOUR = NA0 + NA1 + 2 * NB;  // this wave's LDS-DMA instructions of four half-tiles
+        // ---- P1: quadrant (A0, B0) ----
+        if (TAIL < 2) stage_w<B ^ 1, 1>(kt + 1);
+        read_a<B, 0>();
+        read_b<B, 0>(bf0);
+        if (TAIL < 2) wait_vm<FOUR>(); else wait_vm<NA1>();  // B1(kt) has landed
+        G8_BARRIER();
+        mma<0, 0>(bf0);
+        G8_BARRIER();
+        // ---- P2: (A0, B1) ----
+        if (TAIL < 2) stage_a<B ^ 1, 1, NA1>(kt + 1);
+        read_b<B, 1>(bf1);
+        if (TAIL < 2) wait_vm<FOUR>(); else wait_vm<0>();    // A1(kt) has landed
+        G8_BARRIER();
+        mma<0, 1>(bf1);
+        G8_BARRIER();
+        // ---- P3: (A1, B1) ----
+        if (TAIL == 0) stage_a<B, 0, NA0>(kt + 2);
+        read_a<B, 1>();
+        G8_BARRIER();
+        mma<1, 1>(bf1);
+        G8_BARRIER();
+        // ---- P4: (A1, B0) ----
+        if (TAIL == 0) stage_w<B, 0>(kt + 2);
+        if (TAIL == 0) wait_vm<FOUR>();                      // A0, B0 of K-tile kt+1 have landed
+        else if (TAIL == 1) wait_vm<NB + NA1>();
+        G8_BARRIER();
+        mma<1, 0>(bf0);
+        G8_BARRIER();
+    }
+
+    template <int NA0, int NA1>
+    MM_DEVICE void run(int nk, int grp) {
+        // the vector-memory queue is empty here at run time; saying so keeps the static check of the counted waits
+        // (tools/isa_check.py) independent of how the compiler lays the two code paths out
+        wait_vm<0>();
+        stage_a<0, 0, NA0>(0); stage_w<0, 0>(0); stage_w<0, 1>(0); stage_a<0, 1, NA1>(0);
+        stage_a<1, 0, NA0>(1); stage_w<1, 0>(1);
+        wait_vm<NA0 + NA1 + 2 * NB>();
+        G8_BARRIER();
+        if (grp == 1) G8_BARRIER();  // waves 4-7 run one barrier behind waves 0-3
+        for (int kt = 0; kt + 2 < nk; kt += 2) {
+            tile<0, NA0, NA1, 0>(kt);
+            tile<1, NA0, NA1, 0>(kt + 1);
+        }
+        tile<0, NA0, NA1, 1>(nk - 2);
+        tile<1, NA0, NA1, 2>(nk - 1);
+        if (grp == 0) G8_BARRIER();
+    }
+};
+
+template <int EPI, class G>
+__global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ntm = (g.M + G::BM - 1) / G::BM, ntn = (g.N + G::BN - 1) / G::BN;
+    int mt, nt;
+    tile_coords<1024 / G::BN>(xcd_remap(blockIdx.x, gridDim.x), ntm, ntn, mt, nt);
+    const int m0 = mt * G::BM, n0 = nt * G::BN;
+    G k;
+    k.init(g, m0, n0, wave, threadIdx.x & 63);
+    const int nk = g.K / BK;
+    // The two code paths (waves that move one LDS-DMA piece more per A half-tile) never rejoin with live accumulators:
+    // each runs its own epilogue, which recomputes the lane id so that nothing of its addressing is live across the loop.
+    if (G::REM != 0 && wave < G::REM) {
+        k.template run<G::NPA0 / 8 + (G::RA0 ? 1 : 0), G::NPA1 / 8 + (G::RA1 ? 1 : 0)>(nk, wave >> 2);
+        const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        gemm_epilogue<EPI, G::TM, G::TN, G::WN>(g, m0, n0, k.acc, wave, lane);
+    } else {
+        k.template run<G::NPA0 / 8, G::NPA1 / 8>(nk, wave >> 2);
+        const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        gemm_epilogue<EPI, G::TM, G::TN, G::WN>(g, m0, n0, k.acc, wave, lane);
+    }
+    gemm_publish(g, wave);
+}
+
+template <int EPI, class G>
+int launch_cfg8(const GemmArgs& g, hipStream_t s) {
+    auto fn = gemm8_kernel<EPI, G>;
+    static bool attr_set[16] = {};  // function attributes are per device
+    int dev = 0;
+    MM_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16 || !attr_set[dev]) {
+        MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        if (dev >= 0 && dev < 16) attr_set[dev] = true;
+    }
+    const int ntm = (g.M + G::BM - 1) / G::BM, ntn = (g.N + G::BN - 1) / G::BN;
+    hipLaunchKernelGGL(fn, dim3(ntm * ntn), dim3(512), G::LDS, s, g);
+    MM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+template <int EPI>
+int launch_epi8(int cfg, const GemmArgs& g, hipStream_t s) {
+    switch (cfg) {
+        case GEMM8_320x256: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4>>(g, s);
+        case GEMM8_256x256: return launch_cfg8<EPI, Gemm8<256, 256, 2, 4>>(g, s);
+        case GEMM8_160x256: return launch_cfg8<EPI, Gemm8<160, 256, 2, 4>>(g, s);
+        case GEMM8_320x128: return launch_cfg8<EPI, Gemm8<320, 128, 4, 2>>(g, s);
+    }
+    return mm_fail("gemm8: unknown configuration %d", cfg);
+}
+
+}  // namespace
+
+bool gemm8_supports(const GemmArgs& g) {
+    // two K-tiles per loop iteration and a two-tile tail; whole 8-row LDS-DMA pieces; 32-bit source offsets inside a tile
+    return g.K % 128 == 0 && g.K >= 256 && g.M % 8 == 0 && g.N % 8 == 0 && g.M >= 8 && g.N >= 8 &&
+           (long long)g.lda * 2 * 328 < (1ll << 31) && (long long)g.ldw * 2 * 264 < (1ll << 31);
+}
+
+int launch_gemm8(int epi, int cfg, const GemmArgs& g, hipStream_t s) {
+    if (!gemm8_supports(g)) return mm_fail("gemm8: unsupported shape M=%d N=%d K=%d", g.M, g.N, g.K);
+    switch (epi) {
+        case EPI_STORE: return launch_epi8<EPI_STORE>(cfg, g, s);
+        case EPI_RESID: return launch_epi8<EPI_RESID>(cfg, g, s);
+        case EPI_SWIGLU: return launch_epi8<EPI_SWIGLU>(cfg, g, s);
+        case EPI_QKV: return launch_epi8<EPI_QKV>(cfg, g, s);
+    }
+    return mm_fail("gemm8: bad epilogue %d", epi);
+}

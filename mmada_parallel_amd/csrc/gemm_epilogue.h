@@ -1,0 +1,197 @@
+// gemm_epilogue.h — fused epilogues shared by the two bf16 GEMM kernels (gemm.hip: 16-wave one-barrier-per-K-tile kernel,
+// gemm8.hip: 8-wave 8-phase kernel).  Both hand over fp32 accumulators in the v_mfma_f32_16x16x32_bf16 C layout.
+//
+// Epilogues reproduce the reference's rounding points exactly: every nn.Linear output is rounded to bf16 before
+// anything else touches it (model/modeling_llada.py:925-927, 741-744, 962-970).
+#pragma once
+#include "kernels.h"
+
+namespace gemm_detail {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// RoPE rotation in fp32 with separately rounded products (the reference evaluates t*cos and rotate_half(t)*sin
+// as two tensors and then adds them: model/modeling_llada.py:408-409) — no FMA contraction allowed.
+MM_DEVICE void rope_pair(float t1, float t2, float c, float s, float& o1, float& o2) {
+#pragma clang fp contract(off)
+    float a = t1 * c;
+    float b = t2 * s;
+    o1 = a - b;
+    float e = t2 * c;
+    float f = t1 * s;
+    o2 = e + f;
+}
+
+MM_DEVICE float silu_bf16(float g) {
+    // F.silu on a bf16 tensor: evaluated in fp32, rounded to bf16 (model/modeling_llada.py:477-480)
+    return bfround(g / (1.0f + expf(-g)));
+}
+
+// Tile sequence number -> (row tile, column tile): grouped order, GN column tiles (1024 columns) x all row tiles per group, so
+// workgroups with neighbouring sequence numbers (same XCD after xcd_remap) share A and W panels in their L2.
+template <int GN = 4>
+MM_DEVICE void tile_coords(int t, int ntm, int ntn, int& mt, int& nt) {
+    const int gsize = GN * ntm;
+    const int grp = t / gsize, rem = t - grp * gsize;
+    const int gn = min(GN, ntn - grp * GN);
+    mt = rem / gn;
+    nt = grp * GN + (rem - mt * gn);
+}
+
+// Wave grid WM x WN over the block tile, a wave owns TM x TN outputs = FM x FN fragments of 16 x 16:
+//     acc[mi][ni][r] = D[m][n],  m = m0 + wm*TM + mi*16 + (lane>>4)*4 + r,  n = n0 + wn*TN + ni*16 + (lane&15)
+template <int EPI, int TM, int TN, int WN>
+MM_DEVICE void gemm_epilogue(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[TM / 16][TN / 16], int wave, int lane) {
+    constexpr int FM = TM / 16, FN = TN / 16;
+    static_assert(TN % 32 == 0, "fused epilogues pair adjacent 16-column fragments");
+    const int wm = wave / WN, wn = wave % WN;
+    const int frow = lane & 15, fq = lane >> 4;
+    // ---- epilogue: acc[mi][ni][r] = D[m][n], m = m0+wm*TM+mi*16+fq*4+r, n = n0+wn*TN+ni*16+frow ----
+    const int mrow0 = m0 + wm * TM + fq * 4;
+    const int wcol0 = n0 + wn * TN;  // first column of this wave (wave-uniform)
+
+    if constexpr (EPI == EPI_STORE || EPI == EPI_RESID) {
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mrow0 + mi * 16 + r;
+                if (m >= g.M) continue;
+                // wave-uniform: the 16 rows of a fragment share one residual owner
+                const bool add = EPI == EPI_RESID && (g.resid_mod == 1 || ((m >> 4) % g.resid_mod) == g.resid_rank);
+                size_t rrow = (size_t)m;  // residual row (compact -> full layout when a row window is active)
+                if (EPI == EPI_RESID && g.rwin) {
+                    const int bb = m / g.rwin;
+                    rrow = (size_t)bb * g.rlp + g.rbeg + (m - bb * g.rwin);
+                }
+#pragma unroll
+                for (int ni = 0; ni < FN; ++ni) {
+                    const int n = wcol0 + ni * 16 + frow;
+                    if (n >= g.N) continue;
+                    float v = acc[mi][ni][r];
+                    if constexpr (EPI == EPI_RESID) {
+                        v = bfround(v);
+                        if (add) v = bf2f(g.resid[rrow * g.ldr + n]) + v;
+                    }
+                    g.C[(size_t)m * g.ldc + n] = f2bf(v);
+                }
+            }
+    } else if constexpr (EPI == EPI_SWIGLU) {
+        // columns come in 32-wide groups: [16 x ff_proj | 16 x up_proj] (see pack_gate_up); x = silu(ff_proj)*up
+        if (wcol0 < g.N) {
+            const int hcol0 = wcol0 / 2 + frow;
+#pragma unroll
+            for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mrow0 + mi * 16 + r;
+                    if (m >= g.M) continue;
+#pragma unroll
+                    for (int q2 = 0; q2 < FN / 2; ++q2) {
+                        if (wcol0 + q2 * 32 >= g.N) continue;
+                        const float gate = bfround(acc[mi][2 * q2][r]);
+                        const float up = bfround(acc[mi][2 * q2 + 1][r]);
+                        g.C[(size_t)m * g.ldc + hcol0 + q2 * 16] = f2bf(silu_bf16(gate) * up);
+                    }
+                }
+        }
+    } else {  // EPI_QKV: a wave's TN columns lie inside one 128-wide head
+        const int head = wcol0 >> 7, c0 = wcol0 & 127;
+        if (head < g.Hq + g.Hkv) {
+            const bool isq = head < g.Hq;
+            bf16_t* dst = isq ? g.q : g.k;
+            const int hh = isq ? head : head - g.Hq;
+            const int nh = isq ? g.Hq : g.Hkv;
+#pragma unroll
+            for (int mi = 0; mi < FM; ++mi)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mrow0 + mi * 16 + r;
+                    if (m >= g.M) continue;
+                    const int mg = m + g.m_base;  // row of the whole [B*Lp] stream
+                    const int b = mg / g.Lp;
+                    int l = mg - b * g.Lp;        // rotary position
+                    int lrow = l, lstride = g.Lkv;  // destination row / rows per head
+                    if (g.pos_map) {
+                        const int pos = g.pos_map[mg];
+                        if (isq) {
+                            lrow = l; lstride = g.Lq;
+                            l = g.q_pos_shift >= 0 ? l + g.q_pos_shift : (pos < 0 ? 0 : pos);
+                        } else {
+                            if (pos < 0) continue;  // pad row of the compact stream: never enters the cache
+                            l = lrow = pos;
+                        }
+                    }
+                    bf16_t* row = dst + ((size_t)(b * nh + hh) * lstride + lrow) * 128;
+#pragma unroll
+                    for (int q2 = 0; q2 < FN / 2; ++q2) {
+                        // permuted column layout: fragments (2*q2, 2*q2+1) hold rotary partners i and i+64
+                        const int i = (c0 / 32 + q2) * 16 + frow;
+                        const float t1 = bfround(acc[mi][2 * q2][r]);
+                        const float t2 = bfround(acc[mi][2 * q2 + 1][r]);
+                        const float c = g.rope_cos[l * 64 + i], s = g.rope_sin[l * 64 + i];
+                        float o1, o2;
+                        rope_pair(t1, t2, c, s, o1, o2);
+                        row[i] = f2bf(o1);
+                        row[i + 64] = f2bf(o2);
+                    }
+                }
+        } else if (head < g.Hq + 2 * g.Hkv) {
+            const int hv = head - g.Hq - g.Hkv;
+#pragma unroll
+            for (int mi = 0; mi < FM; ++mi) {
+                const int mb = mrow0 + mi * 16;  // multiple of 4; Lp is a multiple of 8 -> 4 rows share a batch
+                if (mb >= g.M) continue;
+                const int mbg = mb + g.m_base;  // m_base is a multiple of 8: the 4 rows still share a batch element
+                const int b = mbg / g.Lp, l0 = mbg - b * g.Lp;
+                if (g.pos_map) {  // scattered rows: one 2-byte store per (row, d); only the computed rows of a cache step
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (mb + r >= g.M) continue;
+                        const int pos = g.pos_map[mbg + r];
+                        if (pos < 0) continue;
+                        const size_t kp = (size_t)vt_key_pos(pos & ~3) + (pos & 3);
+#pragma unroll
+                        for (int ni = 0; ni < FN; ++ni) {
+                            const int d = c0 + ni * 16 + frow;
+                            g.vT[((size_t)(b * g.Hkv + hv) * 128 + d) * g.Lkv + kp] = f2bf(acc[mi][ni][r]);
+                        }
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int ni = 0; ni < FN; ++ni) {
+                    const int d = c0 + ni * 16 + frow;
+                    u32x2 pk;
+                    pk[0] = pack_bf2(acc[mi][ni][0], acc[mi][ni][1]);
+                    pk[1] = pack_bf2(acc[mi][ni][2], acc[mi][ni][3]);
+                    *(u32x2*)(g.vT + ((size_t)(b * g.Hkv + hv) * 128 + d) * g.Lkv + vt_key_pos(l0)) = pk;
+                }
+            }
+        }
+    }
+}
+
+
+// every workgroup whose C is read by OTHER agents / other XCDs' kernels polling a counter (tensor-parallel partials,
+// csrc/tp_comm.hip) ends with a system-scope release so that its stores have left this XCD's L2
+MM_DEVICE void gemm_publish(const GemmArgs& g, int wave) {
+    if (g.publish) {
+        __syncthreads();
+        if (wave == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+}
+
+}  // namespace gemm_detail
+
+// gemm8.hip: the 8-phase kernel.  cfg = one of the GEMM8_* configurations; returns nonzero on a launch error.
+enum Gemm8Cfg { GEMM8_320x256 = 0, GEMM8_256x256 = 1, GEMM8_160x256 = 2, GEMM8_320x128 = 3, GEMM8_NCFG = 4 };
+bool gemm8_supports(const GemmArgs& g);  // shape contract of the 8-phase kernel (K % 128 == 0, K >= 256, M, N % 8 == 0, ...)
+int launch_gemm8(int epi, int cfg, const GemmArgs& g, hipStream_t s);
+// Measurement hook (tools/gemm_sweep.py, tests): force one configuration for every following launch of this process.
+//   -1: automatic (default);  0..3: GEMM8_* configuration;  1000 + BM: the 16-wave kernel with that row-tile height.
+void gemm_force_config(int code);

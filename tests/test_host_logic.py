@@ -3,6 +3,7 @@ formulas (generators/parallel_generator.py:73-99,157-159,318-321; inference.py:1
 import math
 import os
 
+import pytest
 import torch
 
 from mmada_parallel_amd import synth
@@ -188,3 +189,61 @@ def test_pixel_token_helpers_match_the_reference_functions():
 
     with pytest.raises(ValueError):
         iu.decode_vq_to_image(codes[:, :-1], None, None, 36, 70, vq)
+
+
+def _gemm8_program(nk, na0, na1, nb):
+    """Program order of ONE wave of csrc/gemm8.hip (Gemm8::run / Gemm8::tile): ('stage', half, tile), ('read', half, tile),
+    ('wait', n) and ('phase',) events.  Kept in step with the kernel by hand: it is the specification the kernel follows."""
+    four = na0 + na1 + 2 * nb
+    ev = [("wait", 0)]
+    for n, t in (("A0", 0), ("B0", 0), ("B1", 0), ("A1", 0), ("A0", 1), ("B0", 1)):
+        ev.append(("stage", n, t))
+    ev += [("wait", four), ("phase",)]
+    for T in range(nk):
+        tail = 0 if T + 2 < nk else (1 if T == nk - 2 else 2)
+        if tail < 2:
+            ev.append(("stage", "B1", T + 1))
+        ev += [("read", "A0", T), ("read", "B0", T), ("wait", four if tail < 2 else na1), ("phase",)]
+        if tail < 2:
+            ev.append(("stage", "A1", T + 1))
+        ev += [("read", "B1", T), ("wait", four if tail < 2 else 0), ("phase",)]
+        if tail == 0:
+            ev.append(("stage", "A0", T + 2))
+        ev += [("read", "A1", T), ("phase",)]
+        if tail == 0:
+            ev += [("stage", "B0", T + 2), ("wait", four)]
+        elif tail == 1:
+            ev.append(("wait", nb + na1))
+        ev.append(("phase",))
+    return ev
+
+
+@pytest.mark.parametrize("na0,na1,nb", [(2, 2, 2), (3, 3, 2), (2, 1, 2), (1, 1, 2), (3, 2, 1)])
+def test_gemm8_schedule(na0, na1, nb):
+    """The LDS-DMA queue of the 8-phase GEMM, simulated in program order for every piece split the kernel instantiates:
+    a half-tile is read only after a counted wait of an EARLIER phase retired all its pieces (RAW: the reader may be a
+    wave of the other, one-barrier-late group), a slot is re-staged at least two phases after its last read (WAR), the
+    slot holds the K-tile that is read, and the queue is empty at the end."""
+    cnt = {"A0": na0, "A1": na1, "B0": nb, "B1": nb}
+    for nk in (2, 4, 6, 8, 64, 192):
+        fifo, landed, slot, last_read, ph = [], {}, {}, {}, 0
+        for e in _gemm8_program(nk, na0, na1, nb):
+            if e[0] == "phase":
+                ph += 1
+            elif e[0] == "stage":
+                _, n, t = e
+                assert t < nk
+                lr = last_read.get((t & 1, n))
+                assert lr is None or ph - lr >= 2, f"WAR: {n}{t} staged in phase {ph}, slot last read in phase {lr}"
+                slot[(t & 1, n)] = t
+                fifo += [(n, t)] * cnt[n]
+            elif e[0] == "wait":
+                while len(fifo) > e[1]:
+                    landed[fifo.pop(0)] = ph   # a half-tile has landed when its LAST piece is retired
+            else:
+                _, n, t = e
+                assert slot.get((t & 1, n)) == t, f"slot {n} holds K-tile {slot.get((t & 1, n))} when {t} is read"
+                assert (n, t) not in fifo, f"RAW: {n}{t} still in flight in phase {ph}"
+                assert ph - landed[(n, t)] >= 1, f"RAW: {n}{t} read in the phase of its wait"
+                last_read[(t & 1, n)] = ph
+        assert not fifo

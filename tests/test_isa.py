@@ -1,0 +1,26 @@
+"""Static checks on the gfx950 ISA of the hand-scheduled kernels (tools/isa_check.py): hipcc cross-compiles without a GPU.
+
+* csrc/gemm8.hip: every wait of its LDS-DMA pipeline is a COUNTED vmcnt, which is only meaningful while nothing but
+  LDS-DMA is in the vector-memory queue.  A compiler-inserted register spill or hoisted global access inside the
+  pipelined region would silently break that; the checker walks the control-flow graph of every instantiation.
+* csrc/tp_comm.hip: remote pulls of the tensor-parallel exchange are single 16-byte system-scope loads.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+import isa_check  # noqa: E402
+
+
+def test_gemm8_counted_waits_see_only_lds_dma():
+    report, errors = isa_check.check_gemm8()
+    assert len(report) == 16, report                      # 4 epilogues x 4 tile configurations
+    assert not errors, "\n".join(errors)
+    for name, n_dma, n_wait, _ in report:
+        assert n_dma >= 20 and n_wait >= 12, (name, n_dma, n_wait)
+
+
+def test_tp_pull_transport_uses_16_byte_system_scope_loads():
+    report, errors = isa_check.check_tp_pull()
+    assert not errors, "\n".join(errors)
+    assert {r[0].split("ILi")[-1][:1] for r in report if "reduce" in r[0]} >= {"2", "4", "8"}

@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Static checks on the gfx950 ISA hipcc emits for the hand-scheduled kernels (no GPU needed).
+
+    python tools/isa_check.py            # prints a report, exit code 1 on a violation
+
+The 8-phase GEMM (csrc/gemm8.hip) keeps four half-tiles of LDS-DMA in flight behind COUNTED `s_waitcnt vmcnt(N)`; the
+counts are only meaningful while nothing but LDS-DMA sits in the vector-memory queue.  hipcc knows nothing about that
+contract: a register spill (scratch_store / scratch_load) or a hoisted global access inside the pipelined region would
+enter the same queue.  Rule checked per kernel, in program order: after any foreign vector-memory instruction, the next
+hand-written wait must be `vmcnt(0)` (which is exact whatever is queued); a counted wait with N > 0 there is an error.
+Also checked: no static LDS (the kernel forms LDS addresses from integers, i.e. assumes its dynamic segment starts at 0),
+and every kernel really uses the LDS-DMA saddr form.
+
+The tensor-parallel pull transport (csrc/tp_comm.hip) must read remote memory with ONE 16-byte system-scope load per
+16 bytes (`global_load_dwordx4 ... sc0 sc1`), never as two 8-byte halves (each would use half of every 64-B fabric
+request and the second would re-request the same lines).
+"""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "mmada_parallel_amd", "csrc")
+FOREIGN = re.compile(r"^\s*(scratch_(load|store)|global_(load|store|atomic)(?!_lds)|buffer_(load|store|atomic)|flat_(load|store|atomic))")
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def device_asm(src):
+    """gfx950 assembly text of one translation unit."""
+    out = subprocess.run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-I", CSRC,
+                          os.path.join(CSRC, src), "-o", "-"], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise RuntimeError(out.stderr)
+    return out.stdout
+
+
+def kernels(asm):
+    """name -> list of instruction lines, and name -> metadata dict (from the .amdhsa_ directives)."""
+    body, meta, cur = {}, {}, None
+    for line in asm.splitlines():
+        m = re.match(r"^(_Z\w+):\s*(;.*)?$", line)
+        if m:
+            cur = m.group(1)
+            body[cur] = []
+            continue
+        if line.startswith(".Lfunc_end"):
+            cur = None
+            continue
+        if cur is not None:
+            body[cur].append(line)
+        m = re.match(r"^\s*\.amdhsa_kernel\s+(\S+)", line)
+        if m:
+            meta_cur = m.group(1)
+            meta[meta_cur] = {}
+            continue
+        m = re.match(r"^\s*\.amdhsa_(\w+)\s+(\S+)", line)
+        if m and meta:
+            meta[list(meta)[-1]][m.group(1)] = m.group(2)
+    return body, meta
+
+
+def check_gemm8(asm=None):
+    asm = asm or device_asm("gemm8.hip")
+    body, meta = kernels(asm)
+    report, errors = [], []
+    for name, lines in body.items():
+        if "gemm8_kernel" not in name:
+            continue
+        # Control-flow graph over basic blocks, then a forward may-analysis of one bit: "a foreign vector-memory op may be
+        # in the queue" (set by a foreign op, cleared by any vmcnt(0) wait).  A hand-written counted wait reached with
+        # the bit set is an error.
+        blocks, cur, labels = [], [], {}
+        for ln in lines:
+            s = ln.strip()
+            m = re.match(r"^(\.LBB\w+):", ln)
+            if m:
+                if cur:
+                    blocks.append(cur)
+                cur = []
+                labels[m.group(1)] = len(blocks)
+                continue
+            if not s or s.startswith(".") or (s.startswith(";") and not s.startswith(";;#ASM")):
+                continue
+            cur.append(s)
+            if re.match(r"s_c?branch|s_endpgm|s_setpc", s):
+                blocks.append(cur)
+                cur = []
+        if cur:
+            blocks.append(cur)
+        succ = []
+        for i, b in enumerate(blocks):
+            last = b[-1] if b else ""
+            out = []
+            m = re.match(r"s_c?branch\w*\s+(\.LBB\w+)", last)
+            if m and m.group(1) in labels:
+                out.append(labels[m.group(1)])
+            if not re.match(r"s_branch|s_endpgm|s_setpc", last) and i + 1 < len(blocks):
+                out.append(i + 1)
+            succ.append(out)
+        n_dma = n_saddr = n_wait = n_foreign = 0
+        for b in blocks:
+            for s in b:
+                if s.startswith("global_load_lds_dwordx4"):
+                    n_dma += 1
+                    n_saddr += bool(re.search(r"global_load_lds_dwordx4\s+v\d+,\s*s\[", s))
+                n_foreign += bool(FOREIGN.match(s))
+
+        def transfer(b, dirty, report_to=None):
+            in_asm = False
+            for s in b:
+                if s.startswith(";;#ASMSTART"):
+                    in_asm = True
+                elif s.startswith(";;#ASMEND"):
+                    in_asm = False
+                elif FOREIGN.match(s):
+                    dirty = s.split(";")[0].strip()
+                else:
+                    m = re.match(r"s_waitcnt.*vmcnt\((\d+)\)", s)
+                    if m and int(m.group(1)) == 0:
+                        dirty = None
+                    elif m and in_asm and dirty and report_to is not None:
+                        report_to.append(f"{name}: counted wait vmcnt({m.group(1)}) may follow foreign vector-memory op '{dirty}'")
+            return dirty
+
+        state = [None] * len(blocks)   # dirty-at-entry per block (None = clean / not reached dirty)
+        work = [0]
+        seen = {0}
+        while work:
+            i = work.pop()
+            out = transfer(blocks[i], state[i])
+            for j in succ[i]:
+                if (out and not state[j]) or j not in seen:
+                    if out and not state[j]:
+                        state[j] = out
+                    seen.add(j)
+                    work.append(j)
+        found = []
+        for i in sorted(seen):
+            transfer(blocks[i], state[i], found)
+            n_wait += sum(1 for s in blocks[i] if re.match(r"s_waitcnt vmcnt\(", s))
+        errors += sorted(set(found))
+        lds = int(meta.get(name, {}).get("group_segment_fixed_size", "0"))
+        if lds != 0:
+            errors.append(f"{name}: static LDS of {lds} bytes (the kernel assumes its dynamic LDS segment starts at 0)")
+        if n_dma == 0 or n_saddr != n_dma:
+            errors.append(f"{name}: {n_saddr} of {n_dma} LDS-DMA loads use the scalar-base form")
+        report.append((name, n_dma, n_wait, n_foreign))
+    if not report:
+        errors.append("no gemm8 kernel found")
+    return report, errors
+
+
+def check_tp_pull(asm=None):
+    asm = asm or device_asm("tp_comm.hip")
+    body, _ = kernels(asm)
+    report, errors = [], []
+    for name, lines in body.items():
+        if "tp_reduce_norm_kernel" not in name and "tp_gather_kernel" not in name:
+            continue
+        x4 = sum(1 for ln in lines if re.search(r"global_load_dwordx4 .*sc0 sc1", ln))
+        x2 = sum(1 for ln in lines if re.search(r"global_load_dwordx2 .*sc0 sc1", ln))
+        report.append((name, x4, x2))
+        if x2:
+            errors.append(f"{name}: {x2} system-scope 8-byte loads (remote pulls must be single 16-byte loads)")
+        if x4 == 0:
+            errors.append(f"{name}: no 16-byte system-scope load found")
+    if not report:
+        errors.append("no pull-transport kernel found")
+    return report, errors
+
+
+def main():
+    bad = []
+    rep, err = check_gemm8()
+    for name, n_dma, n_wait, n_foreign in rep:
+        print(f"gemm8  {name[:90]:90s} LDS-DMA {n_dma:3d}  counted waits {n_wait:3d}  foreign VMEM after the first DMA {n_foreign}")
+    bad += err
+    rep, err = check_tp_pull()
+    for name, x4, x2 in rep:
+        print(f"tp     {name[:90]:90s} sc0 sc1 loads: dwordx4 {x4}  dwordx2 {x2}")
+    bad += err
+    for e in bad:
+        print("ERROR:", e)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

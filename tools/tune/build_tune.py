@@ -14,7 +14,7 @@ CSRC = os.path.join(ROOT, "mmada_parallel_amd", "csrc")
 def build(force=False):
     from mmada_parallel_amd.build import _hipcc
 
-    srcs = [os.path.join(HERE, "gemm_var.hip"), os.path.join(HERE, "gemm8.hip"), os.path.join(HERE, "tune_api.hip"), os.path.join(CSRC, "gemm.hip")]
+    srcs = [os.path.join(HERE, "gemm_var.hip"), os.path.join(HERE, "gemm8.hip"), os.path.join(HERE, "tune_api.hip"), os.path.join(CSRC, "gemm.hip"), os.path.join(CSRC, "gemm8.hip")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(s) < os.path.getmtime(LIB) for s in srcs):
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I", CSRC] + srcs + ["-o", LIB]

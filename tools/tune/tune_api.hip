@@ -3,7 +3,7 @@
 #include <cstdarg>
 #include <cstdio>
 
-#include "kernels.h"
+#include "gemm_epilogue.h"
 
 static thread_local char g_err[512] = "";
 
@@ -26,6 +26,14 @@ int mmada_gemm_variant(int variant, const void* A, const void* W, void* C, int M
     GemmArgs g{};
     g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.C = (bf16_t*)C;
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N;
+    // 100: production planner; 300 + c: production with the 8-phase configuration c forced; 1000 + BM: production with the
+    // 16-wave kernel's row tile forced
+    if (variant == 100 || (variant >= 300 && variant < 300 + GEMM8_NCFG) || variant >= 1000) {
+        gemm_force_config(variant == 100 ? -1 : variant >= 1000 ? variant : variant - 300);
+        const int rc = launch_gemm(EPI_STORE, g, (hipStream_t)stream);
+        gemm_force_config(-1);
+        return rc;
+    }
     return launch_gemm_variant(variant, g, (hipStream_t)stream);
 }
 }
