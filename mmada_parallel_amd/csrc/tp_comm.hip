@@ -115,12 +115,15 @@ __global__ void tp_wait_kernel(const uint32_t* seq, TpPeers p, int size, int ran
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
-// 16 bytes of a peer's buffer, system scope (never served from this agent's caches)
-MM_DEVICE u32x4 load_sys16(const bf16_t* p) {
-    const uint64_t* q = (const uint64_t*)p;
-    const uint64_t a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    const uint64_t b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    return u32x4{(uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32)};
+// 16 bytes of a peer's buffer at system scope (sc0 sc1: never served from this agent's caches) as ONE 16-byte request.
+// A relaxed system-scope __hip_atomic_load lowers to an sc0 sc1 load only up to 8 bytes, and two of those per 16 bytes use
+// half of every 64-byte fabric request each and ask for every line twice (round-2 review: 2x read amplification on xGMI).
+// The buffer form carries the cache-policy bits in its aux operand (1 = sc0, 16 = sc1) and is counted by hipcc's own
+// s_waitcnt bookkeeping, unlike an inline-asm load.  `base` must be wave-uniform (a kernel argument): the descriptor is
+// built in SGPRs; the per-lane part is a 32-bit byte offset (mmada_comm_create refuses buffers of 4 GiB or more).
+MM_DEVICE u32x4 load_sys16(const void* base, uint32_t byte_off) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xffffffffu, 0x00020000);
+    return __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 17);
 }
 
 struct ReduceArgs {
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256) void tp_reduce_norm_kernel(ReduceArgs a) {
                 u32x4 pv[TP];
 #pragma unroll
                 for (int j = 0; j < TP; ++j)  // p.part[rank] is this rank's own buffer: one uniform load form, no branch
-                    pv[j] = load_sys16(a.p.part[j] + (size_t)m * a.d + c * 8);
+                    pv[j] = load_sys16(a.p.part[j], ((uint32_t)m * (uint32_t)a.d + c * 8) * 2u);
 #pragma unroll
                 for (int j = 0; j < TP; ++j)  // rank order: the sum is the same on whichever rank owns the row
 #pragma unroll
@@ -184,7 +187,7 @@ __global__ __launch_bounds__(256) void tp_reduce_norm_kernel(ReduceArgs a) {
             } else {
                 for (int j = 0; j < a.size; ++j) {
                     const u32x4 v = (j == a.rank) ? ((const u32x4*)(a.part + (size_t)m * a.d))[c]
-                                                  : load_sys16(a.p.part[j] + (size_t)m * a.d + c * 8);
+                                                  : load_sys16(a.p.part[j], ((uint32_t)m * (uint32_t)a.d + c * 8) * 2u);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         acc[2 * e] += __uint_as_float(v[e] << 16);
@@ -237,10 +240,14 @@ __global__ __launch_bounds__(256) void tp_gather_kernel(TpPeers p, int rank, int
     const int owner = (m - m0) / slice;
     if (owner == rank) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");  // see tp_reduce_norm_kernel
-    const bf16_t* src = (use_part ? p.part[owner] : p.hn[owner]) + (size_t)m * d;
+    // one row per wave: the owner IS wave-uniform, but it derives from threadIdx and the compiler cannot prove it — say so,
+    // so that the buffer descriptor is built once in SGPRs (no per-lane waterfall loop around every load, guide T20)
+    const int owner_u = __builtin_amdgcn_readfirstlane(owner);
+    const bf16_t* src = use_part ? p.part[owner_u] : p.hn[owner_u];
     const int nchunk = d >> 3;
 #pragma unroll 8
-    for (int c = threadIdx.x & 63; c < nchunk; c += 64) ((u32x4*)(dst + (size_t)m * d))[c] = load_sys16(src + c * 8);
+    for (int c = threadIdx.x & 63; c < nchunk; c += 64)
+        ((u32x4*)(dst + (size_t)m * d))[c] = load_sys16(src, ((uint32_t)m * (uint32_t)d + c * 8) * 2u);
 }
 
 __global__ __launch_bounds__(256) void copy_rows_kernel(const bf16_t* src, bf16_t* dst, int r0, int r1, int d) {
@@ -274,12 +281,10 @@ __global__ void tp_text_combine_kernel(TpPeers p, int size, int rank, const Text
         if (gathered) st[j] = gathered[(size_t)j * stat_stride + row];
         else if (j == rank) st[j] = own[row];
         else {
-            const uint64_t* q = (const uint64_t*)(p.stats[j] + row);
-            const uint64_t a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            const uint64_t b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            st[j].lmax = __uint_as_float((uint32_t)a);
-            st[j].arg = (int32_t)(a >> 32);
-            st[j].sum = __longlong_as_double((long long)b);
+            const u32x4 v = load_sys16(p.stats[j], (uint32_t)row * 16u);  // one 16-byte record
+            st[j].lmax = __uint_as_float(v[0]);
+            st[j].arg = (int32_t)v[1];
+            st[j].sum = __longlong_as_double((long long)(((uint64_t)v[3] << 32) | v[2]));
         }
     }
     float mx = -INFINITY;
@@ -559,6 +564,8 @@ int mmada_comm_create(mmada_handle* h, int max_rows, void* export_out) {
     c->rank = h->cfg.tp_rank; c->size = h->cfg.tp_size; c->d = h->cfg.d_model;
     c->max_rows = max_rows;
     const size_t rows = (size_t)max_rows + 8 * c->size;
+    if (rows * (size_t)h->cfg.d_model * 2 >= (1ull << 32))
+        return mm_fail("mmada_comm_create: %zu rows x %d exceed the 4 GiB the pull kernels address with 32-bit offsets", rows, h->cfg.d_model);
     const size_t bytes = rows * c->d * 2;
     // The hand-off counters and the 16-byte text records are read by other agents while their owner keeps writing them:
     // fine-grained (coherent) device memory when the runtime grants it.  The two bandwidth-critical buffers (partials,

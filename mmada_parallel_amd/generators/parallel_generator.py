@@ -184,6 +184,10 @@ def _ti2ti_steps(
         uncon_image = uncon_image.to(device=device, dtype=torch.long)
 
     # ---- every buffer a step touches exists before the loop (fixed addresses: a step can be captured and replayed) ----
+    # That includes the library's activation workspace: an image step's unconditional pair is a 2B forward, and a workspace
+    # that grows THEN would leave an already captured text-step graph pointing into the freed allocation.
+    if hasattr(model, "_ensure_ws"):
+        model._ensure_ws(2 * B if need_uncond else B, L)
     CBs = codebook_size
     k_cur = torch.zeros(B, dtype=torch.int32, device=device)
     mlen_cur = torch.zeros(1, dtype=torch.int32, device=device)
@@ -266,6 +270,7 @@ def _ti2ti_steps(
     graph = (bool(graph) and temperature == 0 and text_temperature == 0 and remasking == 'low_confidence'
              and model.graph_capturable())  # a replayed step would replay its random draws
     graphs, seen = {}, set()
+    ws_epoch = getattr(model, "_ws_epoch", 0)
     side = torch.cuda.Stream(device=device) if graph else None
     if graph:  # the legacy default stream cannot be captured: the loop runs on a side stream, ordered after the caller's
         side.wait_stream(torch.cuda.current_stream(device))
@@ -284,6 +289,13 @@ def _ti2ti_steps(
                     # ahead of the step's launches
                     noise_buf.copy_(rng.randn((B, N), torch.bfloat16, device, generator))
                 key = (is_img, need_text)
+                if graph and graphs and getattr(model, "_ws_epoch", 0) != ws_epoch:
+                    # the workspace moved after all (a foreign forward in between): captured pointers are stale
+                    for g_old in graphs.values():
+                        lib.mmada_graph_destroy(g_old)
+                    graphs.clear()
+                    seen.clear()
+                ws_epoch = getattr(model, "_ws_epoch", 0)
                 if graph and key in graphs:
                     abi.check(lib.mmada_graph_launch(graphs[key], abi.stream_ptr()), "mmada_graph_launch")
                     model.graph_replays += 1

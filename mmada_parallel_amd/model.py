@@ -98,6 +98,7 @@ class LLaDAForMultiModalGeneration:
         self._ws = None
         self._ws1 = None
         self._ws_bytes = [0, 0]  # bytes registered with the library per activation context
+        self._ws_epoch = 0       # bumped whenever a workspace is (re)allocated: captured step graphs hold its addresses
         self.graph_replays, self.graph_nodes = 0, {}  # hipGraph step replays issued / nodes per captured step kind
         self._comm_in_library, self._comm_rows, self.tp_collective = False, 0, None
         self._handle1 = None
@@ -191,6 +192,7 @@ class LLaDAForMultiModalGeneration:
             base = (ws.data_ptr() + 255) // 256 * 256
             abi.check(self._lib.mmada_set_workspace(h, base, grow), "mmada_set_workspace")
             self._ws_bytes[lane] = grow
+            self._ws_epoch += 1
             if lane == 0:
                 self._ws = ws
             else:

@@ -147,8 +147,8 @@ class ReplayCpuRng:
         return torch.multinomial(probs2d.cpu(), 1, generator=generator).to(probs2d.device)
 
 
-# ---- measured parity numbers (tests/test_gpu_parity_depth.py, test_gpu_fullsize.py) -> gpurun_out/r02_parity.json ----
-PARITY_REPORT = os.path.join(ROOT, "gpurun_out", "r02_parity.json")
+# ---- measured parity numbers (tests/test_gpu_parity_depth.py, test_gpu_fullsize.py) -> gpurun_out/r03_parity.json (copied to profiles/ after a full suite run) ----
+PARITY_REPORT = os.path.join(ROOT, "gpurun_out", "r03_parity.json")
 
 
 def save_parity(section, payload):
@@ -263,3 +263,39 @@ PAINT_UTIL_CASES = {
 def paint_util_image():
     rng = np.random.default_rng(5)
     return rng.integers(0, 256, size=(36, 70, 3), dtype=np.uint8)       # resized to 36 x 70 -> multiples of 2: unchanged size
+
+
+# ---- in-process tensor-parallel rank groups (tests/test_gpu_tp.py, tests/test_gpu_parity_depth.py) ----
+def tp_group(cfg_base, sd, tp, max_rows, dev="cuda:0"):
+    """The ranks of a tensor-parallel group as separate handles of ONE process, each on its own stream, connected with
+    mmada_comm_connect_local (tests/test_gpu_tp.py explains why this is the multi-device code path unchanged)."""
+    import ctypes as C
+
+    from mmada_parallel_amd import LLaDAForMultiModalGeneration, abi
+
+    cfg = synth.full_config(cfg_base)
+    ranks = [LLaDAForMultiModalGeneration.from_state_dict(cfg, sd, device=dev, tp_rank=r, tp_size=tp) for r in range(tp)]
+    lib = ranks[0]._lib
+    for m in ranks:
+        abi.check(lib.mmada_comm_create(m._handle, max_rows, None), "comm_create")
+        m._comm_rows = max_rows
+    arr = (C.c_void_p * tp)(*[m._handle.value for m in ranks])
+    for m in ranks:
+        abi.check(lib.mmada_comm_connect_local(m._handle, arr), "connect_local")
+        m._comm_in_library, m.tp_collective = True, "pull"
+    streams = [torch.cuda.Stream(device=dev) for _ in ranks]
+    return ranks, streams
+
+
+def tp_each(ranks, streams, fn):
+    """fn(rank_model) enqueued for every rank on its own stream; NO host sync until all are enqueued."""
+    out = []
+    cur = torch.cuda.current_stream()
+    for m, s in zip(ranks, streams):
+        s.wait_stream(cur)
+        with torch.cuda.stream(s):
+            out.append(fn(m))
+    for s in streams:
+        cur.wait_stream(s)
+    torch.cuda.synchronize()
+    return out

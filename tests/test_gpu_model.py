@@ -901,3 +901,28 @@ def test_graph_replayed_steps_are_bit_identical_to_eager(tiny_model, case):
     assert kw["text_steps"] - 4 <= tiny_model.graph_replays <= kw["text_steps"] - len(tiny_model.graph_nodes)
     assert all(n > 10 for n in tiny_model.graph_nodes.values()), tiny_model.graph_nodes
     print(f"{case}: {tiny_model.graph_replays} replays, nodes per step kind {tiny_model.graph_nodes}, image steps {n_img}")
+
+
+def test_graph_with_a_batch_whose_unconditional_pair_outgrows_the_default_workspace():
+    """Round-2 advisor finding: with the default max_batch (3) a batch of 2 with unconditional prompts runs its first 4-row
+    forward only at the first image step — AFTER the text-only step graph was captured.  The workspace is now sized before
+    the loop (and captured graphs are dropped if it ever moves): a fresh model, batch 2, graph on == eager, bit for bit."""
+    from mmada_parallel_amd import LLaDAForMultiModalGeneration, generate_ti2ti
+
+    job, kw = tiny_job(), SAMPLER_CASES["img4"]
+    ids = job["input_ids"].repeat(2, 1)
+    ids[1, :4] = torch.tensor([11, 12, 13, 14])
+    ut, ui = job["uncon_text"].repeat(2, 1), job["uncon_image"].repeat(2, 1)
+
+    def run(graph):
+        model = LLaDAForMultiModalGeneration.from_state_dict(synth.full_config(synth.CFG_TINY), tiny_sd(), device=DEV)
+        assert model.max_batch == 3 and model._ws_bytes[0] == 0
+        out = generate_ti2ti(model, ids.to(DEV), job["text_start"], job["text_end"], job["image_start"], job["seq_len"],
+                             job["newline_every"], temperature=0.0, text_temperature=0.0, uncon_text=ut, uncon_image=ui,
+                             return_state=True, graph=graph, **kw)
+        return out[2], model
+
+    eager, _ = run(False)
+    captured, model = run(True)
+    assert model.graph_replays > 0 and model._ws_epoch == 1, "one allocation, before the first capture"
+    assert torch.equal(eager, captured)

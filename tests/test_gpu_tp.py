@@ -14,7 +14,7 @@ import os
 import pytest
 import torch
 
-from helpers import tiny_job, tiny_sd
+from helpers import tiny_job, tiny_sd, tp_each, tp_group
 from mmada_parallel_amd import abi, synth
 
 pytestmark = pytest.mark.gpu
@@ -22,35 +22,7 @@ DEV = "cuda:0"
 os.environ.setdefault("MMADA_TP_TIMEOUT_S", "8")
 
 
-def _group(cfg_base, sd, tp, max_rows):
-    from mmada_parallel_amd import LLaDAForMultiModalGeneration
-
-    cfg = synth.full_config(cfg_base)
-    ranks = [LLaDAForMultiModalGeneration.from_state_dict(cfg, sd, device=DEV, tp_rank=r, tp_size=tp) for r in range(tp)]
-    lib = ranks[0]._lib
-    for m in ranks:
-        abi.check(lib.mmada_comm_create(m._handle, max_rows, None), "comm_create")
-        m._comm_rows = max_rows
-    arr = (C.c_void_p * tp)(*[m._handle.value for m in ranks])
-    for m in ranks:
-        abi.check(lib.mmada_comm_connect_local(m._handle, arr), "connect_local")
-        m._comm_in_library, m.tp_collective = True, "pull"
-    streams = [torch.cuda.Stream(device=DEV) for _ in ranks]
-    return ranks, streams
-
-
-def _each(ranks, streams, fn):
-    """fn(rank_model) enqueued for every rank on its own stream; NO host sync until all are enqueued."""
-    out = []
-    cur = torch.cuda.current_stream()
-    for m, s in zip(ranks, streams):
-        s.wait_stream(cur)
-        with torch.cuda.stream(s):
-            out.append(fn(m))
-    for s in streams:
-        cur.wait_stream(s)
-    torch.cuda.synchronize()
-    return out
+_group, _each = tp_group, tp_each
 
 
 @pytest.mark.parametrize("chunks", ["2", "1"])

@@ -164,13 +164,16 @@ def check_tp_pull(asm=None):
     for name, lines in body.items():
         if "tp_reduce_norm_kernel" not in name and "tp_gather_kernel" not in name:
             continue
-        x4 = sum(1 for ln in lines if re.search(r"global_load_dwordx4 .*sc0 sc1", ln))
-        x2 = sum(1 for ln in lines if re.search(r"global_load_dwordx2 .*sc0 sc1", ln))
+        x4 = sum(1 for ln in lines if re.search(r"(global|buffer)_load_dwordx4 .*sc0 sc1", ln))
+        x2 = sum(1 for ln in lines if re.search(r"(global|buffer|flat)_load_(dword|dwordx2|dwordx3) .*sc0 sc1", ln))
         report.append((name, x4, x2))
         if x2:
-            errors.append(f"{name}: {x2} system-scope 8-byte loads (remote pulls must be single 16-byte loads)")
+            errors.append(f"{name}: {x2} narrow system-scope loads (remote pulls must be single 16-byte loads)")
         if x4 == 0:
             errors.append(f"{name}: no 16-byte system-scope load found")
+        # a buffer descriptor hipcc cannot prove wave-uniform is wrapped in a v_readfirstlane / s_and_saveexec loop per load
+        if any("v_readfirstlane" in ln for ln in lines) and sum("s_and_saveexec" in ln for ln in lines) > 2:
+            errors.append(f"{name}: waterfall loops around the buffer loads (descriptor not provably wave-uniform)")
     if not report:
         errors.append("no pull-transport kernel found")
     return report, errors
