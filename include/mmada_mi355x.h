@@ -330,6 +330,15 @@ size_t mmada_vq_group_norm_scratch_bytes(int B);
 int mmada_profile_begin(mmada_handle* h, int layer);
 int mmada_profile_end(mmada_handle* h, int32_t* count_out /*[5]*/, double* ms_out /*[5]*/, double* flops_out /*[5]*/);
 
+/* ---- attainable-MFMA probe (bench.py's roofline.attainable_tflops; measurement only, no reference counterpart) -----
+ * Runs `launches` launches of an MFMA-only kernel (v_mfma_f32_16x16x32_bf16 on register-resident operand fragments taken
+ * from `data`, eight waves per CU, no memory / LDS / barrier traffic) on `stream`, synchronises, and returns the achieved
+ * dense TFLOP/s and the elapsed milliseconds.  `data`: device, >= mmada_mfma_probe_bytes() bytes of bf16 the caller
+ * filled with RANDOM values (zeros clock ~20 % higher: MI355X runs this load at its package power limit); `sink`: 4 bytes
+ * of device scratch.  iters = 32768 is ~50 ms per launch. */
+size_t mmada_mfma_probe_bytes(void);
+int mmada_mfma_probe(const void* data, void* sink, int iters, int launches, void* stream, double* tflops_out, double* ms_out);
+
 /* ---- tensor-parallel exchange inside the library (SURVEY.md §8b mmada_allreduce_init, §8e) ----------------------------
  * New design; the reference runs one replica (inference.py:83-85).  With tp_size > 1 the two row-parallel GEMMs of a block
  * (attn_out, ff_out; model/modeling_llada.py:741-744, 968-970) leave a partial [B*Lp, d] sum on every rank.  One exchange

@@ -71,6 +71,8 @@ SIGNATURES = {
     "mmada_lfq_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mmada_profile_begin": (c_int, [c_void_p, c_int]),
     "mmada_profile_end": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mmada_mfma_probe_bytes": (c_size_t, []),
+    "mmada_mfma_probe": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mmada_gemm_bt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mmada_rmsnorm": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "mmada_vq_create": (c_int, [c_void_p, C.POINTER(c_void_p)]),

@@ -297,6 +297,13 @@ int mmada_profile_end(mmada_handle* h, int32_t* count_out, double* ms_out, doubl
     return 0;
 }
 
+size_t mmada_mfma_probe_bytes(void) { return (size_t)64 * 8 * 16 * 64 * 16; }
+
+int mmada_mfma_probe(const void* data, void* sink, int iters, int launches, void* stream, double* tflops_out, double* ms_out) {
+    if (!data || !sink || iters <= 0 || launches <= 0) return mm_fail("mmada_mfma_probe: bad argument");
+    return launch_mfma_probe((const bf16_t*)data, (float*)sink, iters, launches, (hipStream_t)stream, tflops_out, ms_out);
+}
+
 void* mmada_stream_ptr(mmada_handle* h) { return h ? (void*)h->x : nullptr; }
 size_t mmada_stream_bytes(const mmada_handle* h) { return h ? (size_t)h->Mcur * h->cfg.d_model * 2 : 0; }
 

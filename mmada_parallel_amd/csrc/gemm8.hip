@@ -61,9 +61,12 @@ MM_DEVICE void wait_vm() {
     G8_SB();
 }
 
-template <int BM_, int BN_, int WM_, int WN_>
+// SW: operand roles of the MFMAs.  0: (activation, weight) — the C layout of gemm_epilogue;  1: swapped, the transposed C
+// layout of gemm_epilogue_t (a lane owns four consecutive columns of a row: 8-byte epilogue accesses);  2: chosen per wave
+// (`swap`): the QKV projection, whose V waves want the untransposed layout.  Same products, same k order: same bits.
+template <int BM_, int BN_, int WM_, int WN_, int SW_>
 struct Gemm8 {
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, SW = SW_;
     static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
     static constexpr int FA0 = (FM + 1) / 2, FA1 = FM / 2, FB = FN / 2;  // fragments of the A halves / of a W half
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES, LDS = 2 * STAGE;
@@ -172,7 +175,7 @@ struct Gemm8 {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) bf[nj][kk] = *lds_frag(rb[B][kk] + (H * FB * 16 + nj * 16) * 128);
     }
-    template <int H, int NH>
+    template <int H, int NH, bool SWAP>
     MM_DEVICE void mma(bf16x8 (&bf)[FB][2]) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
@@ -181,13 +184,15 @@ struct Gemm8 {
 #pragma unroll
                 for (int nj = 0; nj < FB; ++nj) {
                     f32x4& c = acc[(H ? FA0 : 0) + mi][NH * FB + nj];
-                    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][kk], bf[nj][kk], c, 0, 0, 0);
+                    c = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nj][kk], af[mi][kk], c, 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][kk], bf[nj][kk], c, 0, 0, 0);
                 }
     }
 
+
     // One K-tile (index kt, LDS buffer B).  TAIL 0: steady state (kt + 2 < nk); 1: second-to-last; 2: last K-tile.
     // LDS-DMA queue, oldest first, at the top of P1(kt): B1(kt) A1(kt) A0(kt+1) B0(kt+1)  (A0, B0 of kt have landed).
-    template <int B, int NA0, int NA1, int TAIL>
+    template <int B, int NA0, int NA1, int TAIL, bool SWAP>
     MM_DEVICE void tile(int kt) {
         constexpr int FOUR = NA0 + NA1 + 2 * NB;  // this wave's LDS-DMA instructions of four half-tiles
         // ---- P1: quadrant (A0, B0) ----
@@ -196,31 +201,31 @@ struct Gemm8 {
         read_b<B, 0>(bf0);
         if (TAIL < 2) wait_vm<FOUR>(); else wait_vm<NA1>();  // B1(kt) has landed
         G8_BARRIER();
-        mma<0, 0>(bf0);
+        mma<0, 0, SWAP>(bf0);
         G8_BARRIER();
         // ---- P2: (A0, B1) ----
         if (TAIL < 2) stage_a<B ^ 1, 1, NA1>(kt + 1);
         read_b<B, 1>(bf1);
         if (TAIL < 2) wait_vm<FOUR>(); else wait_vm<0>();    // A1(kt) has landed
         G8_BARRIER();
-        mma<0, 1>(bf1);
+        mma<0, 1, SWAP>(bf1);
         G8_BARRIER();
         // ---- P3: (A1, B1) ----
         if (TAIL == 0) stage_a<B, 0, NA0>(kt + 2);
         read_a<B, 1>();
         G8_BARRIER();
-        mma<1, 1>(bf1);
+        mma<1, 1, SWAP>(bf1);
         G8_BARRIER();
         // ---- P4: (A1, B0) ----
         if (TAIL == 0) stage_w<B, 0>(kt + 2);
         if (TAIL == 0) wait_vm<FOUR>();                      // A0, B0 of K-tile kt+1 have landed
         else if (TAIL == 1) wait_vm<NB + NA1>();
         G8_BARRIER();
-        mma<1, 0>(bf0);
+        mma<1, 0, SWAP>(bf0);
         G8_BARRIER();
     }
 
-    template <int NA0, int NA1>
+    template <int NA0, int NA1, bool SWAP>
     MM_DEVICE void run(int nk, int grp) {
         // the vector-memory queue is empty here at run time; saying so keeps the static check of the counted waits
         // (tools/isa_check.py) independent of how the compiler lays the two code paths out
@@ -231,11 +236,11 @@ struct Gemm8 {
         G8_BARRIER();
         if (grp == 1) G8_BARRIER();  // waves 4-7 run one barrier behind waves 0-3
         for (int kt = 0; kt + 2 < nk; kt += 2) {
-            tile<0, NA0, NA1, 0>(kt);
-            tile<1, NA0, NA1, 0>(kt + 1);
+            tile<0, NA0, NA1, 0, SWAP>(kt);
+            tile<1, NA0, NA1, 0, SWAP>(kt + 1);
         }
-        tile<0, NA0, NA1, 1>(nk - 2);
-        tile<1, NA0, NA1, 2>(nk - 1);
+        tile<0, NA0, NA1, 1, SWAP>(nk - 2);
+        tile<1, NA0, NA1, 2, SWAP>(nk - 1);
         if (grp == 0) G8_BARRIER();
     }
 };
@@ -250,17 +255,27 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     G k;
     k.init(g, m0, n0, wave, threadIdx.x & 63);
     const int nk = g.K / BK;
-    // The two code paths (waves that move one LDS-DMA piece more per A half-tile) never rejoin with live accumulators:
-    // each runs its own epilogue, which recomputes the lane id so that nothing of its addressing is live across the loop.
-    if (G::REM != 0 && wave < G::REM) {
-        k.template run<G::NPA0 / 8 + (G::RA0 ? 1 : 0), G::NPA1 / 8 + (G::RA1 ? 1 : 0)>(nk, wave >> 2);
-        const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        gemm_epilogue<EPI, G::TM, G::TN, G::WN>(g, m0, n0, k.acc, wave, lane);
-    } else {
-        k.template run<G::NPA0 / 8, G::NPA1 / 8>(nk, wave >> 2);
-        const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        gemm_epilogue<EPI, G::TM, G::TN, G::WN>(g, m0, n0, k.acc, wave, lane);
+    // Up to four self-contained code paths (a wave moves one LDS-DMA piece more per A half-tile or not; operand roles
+    // swapped or not): they never rejoin with live accumulators — each runs its own epilogue, which recomputes the lane
+    // id so that nothing of its addressing is live across the main loop.
+    const bool extra = G::REM != 0 && wave < G::REM;
+    const bool swap = G::SW == 1 || (G::SW == 2 && !qkv_wave_is_v(g, n0 + (wave % G::WN) * G::TN));
+    constexpr int NA0 = G::NPA0 / 8, NA1 = G::NPA1 / 8, XA0 = NA0 + (G::RA0 ? 1 : 0), XA1 = NA1 + (G::RA1 ? 1 : 0);
+#define G8_PATH(A0, A1, SWP)                                                                        \
+    do {                                                                                            \
+        k.template run<A0, A1, SWP>(nk, wave >> 2);                                                 \
+        const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));        \
+        if (SWP) gemm_epilogue_t<EPI, G::TM, G::TN, G::WN>(g, m0, n0, k.acc, wave, lane);           \
+        else gemm_epilogue<EPI, G::TM, G::TN, G::WN>(g, m0, n0, k.acc, wave, lane);                 \
+    } while (0)
+    if (G::SW != 0 && swap) {
+        if (extra) G8_PATH(XA0, XA1, true);
+        else G8_PATH(NA0, NA1, true);
+    } else if (G::SW != 1) {
+        if (extra) G8_PATH(XA0, XA1, false);
+        else G8_PATH(NA0, NA1, false);
     }
+#undef G8_PATH
     gemm_publish(g, wave);
 }
 
@@ -282,11 +297,12 @@ int launch_cfg8(const GemmArgs& g, hipStream_t s) {
 
 template <int EPI>
 int launch_epi8(int cfg, const GemmArgs& g, hipStream_t s) {
+    constexpr int SW = EPI == EPI_QKV ? 2 : 1;
     switch (cfg) {
-        case GEMM8_320x256: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4>>(g, s);
-        case GEMM8_256x256: return launch_cfg8<EPI, Gemm8<256, 256, 2, 4>>(g, s);
-        case GEMM8_160x256: return launch_cfg8<EPI, Gemm8<160, 256, 2, 4>>(g, s);
-        case GEMM8_320x128: return launch_cfg8<EPI, Gemm8<320, 128, 4, 2>>(g, s);
+        case GEMM8_320x256: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW>>(g, s);
+        case GEMM8_256x256: return launch_cfg8<EPI, Gemm8<256, 256, 2, 4, SW>>(g, s);
+        case GEMM8_160x256: return launch_cfg8<EPI, Gemm8<160, 256, 2, 4, SW>>(g, s);
+        case GEMM8_320x128: return launch_cfg8<EPI, Gemm8<320, 128, 4, 2, SW>>(g, s);
     }
     return mm_fail("gemm8: unknown configuration %d", cfg);
 }

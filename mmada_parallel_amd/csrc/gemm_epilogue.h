@@ -174,6 +174,129 @@ MM_DEVICE void gemm_epilogue(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[TM 
 }
 
 
+// The same epilogues for TRANSPOSED accumulators: the 8-phase kernel issues its MFMAs with the operand roles swapped
+// (W fragment as the A operand, activation fragment as the B operand), which computes the transposed 16 x 16 block with the
+// same products in the same k order:
+//     acc[mi][ni][r] = D[m][n],  m = m0 + wm*TM + mi*16 + (lane&15),  n = n0 + wn*TN + ni*16 + (lane>>4)*4 + r
+// — a lane now owns FOUR CONSECUTIVE COLUMNS of one row, so every residual read, rotary-table read and output write of a
+// lane is one 8- or 16-byte access instead of four 2-byte ones (a 160 x 64 wave tile: 40 instead of 160 store
+// instructions per lane; the epilogue of a short-K launch such as attn_out was ~30 % of its time, round-3 profile).
+// The V columns of the QKV projection are the exception: vT is K-major, so there the untransposed layout (four consecutive
+// KEYS of one feature per lane) is the coalesced one — gemm8 picks the operand order per wave (qkv_wave_is_v).
+MM_DEVICE bool qkv_wave_is_v(const GemmArgs& g, int wcol0) { return (wcol0 >> 7) >= g.Hq + g.Hkv; }
+
+template <int EPI, int TM, int TN, int WN>
+MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[TM / 16][TN / 16], int wave, int lane) {
+    constexpr int FM = TM / 16, FN = TN / 16;
+    static_assert(TN % 32 == 0, "fused epilogues pair adjacent 16-column fragments");
+    const int wm = wave / WN, wn = wave % WN;
+    const int lrow = lane & 15, lq = lane >> 4;
+    const int mrow0 = m0 + wm * TM + lrow;
+    const int wcol0 = n0 + wn * TN;  // first column of this wave (wave-uniform)
+
+    if constexpr (EPI == EPI_STORE || EPI == EPI_RESID) {
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) {
+            const int m = mrow0 + mi * 16;
+            if (m >= g.M) continue;
+            // wave-uniform: the 16 rows of a fragment share one residual owner
+            const bool add = EPI == EPI_RESID && (g.resid_mod == 1 || ((m >> 4) % g.resid_mod) == g.resid_rank);
+            size_t rrow = (size_t)m;  // residual row (compact -> full layout when a row window is active)
+            if (EPI == EPI_RESID && g.rwin) {
+                const int bb = m / g.rwin;
+                rrow = (size_t)bb * g.rlp + g.rbeg + (m - bb * g.rwin);
+            }
+#pragma unroll
+            for (int ni = 0; ni < FN; ++ni) {
+                const int n = wcol0 + ni * 16 + lq * 4;
+                if (n >= g.N) continue;  // N is a multiple of 8 here: a lane's four columns are all inside or all outside
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r];
+                if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = bfround(v[r]);
+                    if (add) {
+                        const u32x2 rv = *(const u32x2*)(g.resid + rrow * g.ldr + n);
+                        v[0] += __uint_as_float(rv[0] << 16);
+                        v[1] += __uint_as_float(rv[0] & 0xffff0000u);
+                        v[2] += __uint_as_float(rv[1] << 16);
+                        v[3] += __uint_as_float(rv[1] & 0xffff0000u);
+                    }
+                }
+                u32x2 pk;
+                pk[0] = pack_bf2(v[0], v[1]);
+                pk[1] = pack_bf2(v[2], v[3]);
+                *(u32x2*)(g.C + (size_t)m * g.ldc + n) = pk;
+            }
+        }
+    } else if constexpr (EPI == EPI_SWIGLU) {
+        // columns come in 32-wide groups: [16 x ff_proj | 16 x up_proj] (see pack_gate_up); x = silu(ff_proj)*up
+        if (wcol0 < g.N) {
+            const int hcol0 = wcol0 / 2 + lq * 4;
+#pragma unroll
+            for (int mi = 0; mi < FM; ++mi) {
+                const int m = mrow0 + mi * 16;
+                if (m >= g.M) continue;
+#pragma unroll
+                for (int q2 = 0; q2 < FN / 2; ++q2) {
+                    if (wcol0 + q2 * 32 >= g.N) continue;
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        o[r] = silu_bf16(bfround(acc[mi][2 * q2][r])) * bfround(acc[mi][2 * q2 + 1][r]);
+                    u32x2 pk;
+                    pk[0] = pack_bf2(o[0], o[1]);
+                    pk[1] = pack_bf2(o[2], o[3]);
+                    *(u32x2*)(g.C + (size_t)m * g.ldc + hcol0 + q2 * 16) = pk;
+                }
+            }
+        }
+    } else {  // EPI_QKV, q and k heads (a wave's TN columns lie inside one 128-wide head; V waves never come here)
+        const int head = wcol0 >> 7, c0 = wcol0 & 127;
+        const bool isq = head < g.Hq;
+        bf16_t* dst = isq ? g.q : g.k;
+        const int hh = isq ? head : head - g.Hq;
+        const int nh = isq ? g.Hq : g.Hkv;
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) {
+            const int m = mrow0 + mi * 16;
+            if (m >= g.M) continue;
+            const int mg = m + g.m_base;  // row of the whole [B*Lp] stream
+            const int b = mg / g.Lp;
+            int l = mg - b * g.Lp;        // rotary position
+            int lr = l, lstride = g.Lkv;  // destination row / rows per head
+            if (g.pos_map) {
+                const int pos = g.pos_map[mg];
+                if (isq) {
+                    lr = l; lstride = g.Lq;
+                    l = g.q_pos_shift >= 0 ? l + g.q_pos_shift : (pos < 0 ? 0 : pos);
+                } else {
+                    if (pos < 0) continue;  // pad row of the compact stream: never enters the cache
+                    l = lr = pos;
+                }
+            }
+            bf16_t* row = dst + ((size_t)(b * nh + hh) * lstride + lr) * 128;
+#pragma unroll
+            for (int q2 = 0; q2 < FN / 2; ++q2) {
+                // permuted column layout: fragments (2*q2, 2*q2+1) hold rotary partners i and i+64
+                const int i = (c0 / 32 + q2) * 16 + lq * 4;
+                const f32x4 cv = *(const f32x4*)(g.rope_cos + l * 64 + i);
+                const f32x4 sv = *(const f32x4*)(g.rope_sin + l * 64 + i);
+                float o1[4], o2[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    rope_pair(bfround(acc[mi][2 * q2][r]), bfround(acc[mi][2 * q2 + 1][r]), cv[r], sv[r], o1[r], o2[r]);
+                u32x2 p1, p2;
+                p1[0] = pack_bf2(o1[0], o1[1]); p1[1] = pack_bf2(o1[2], o1[3]);
+                p2[0] = pack_bf2(o2[0], o2[1]); p2[1] = pack_bf2(o2[2], o2[3]);
+                *(u32x2*)(row + i) = p1;
+                *(u32x2*)(row + i + 64) = p2;
+            }
+        }
+    }
+}
+
 // every workgroup whose C is read by OTHER agents / other XCDs' kernels polling a counter (tensor-parallel partials,
 // csrc/tp_comm.hip) ends with a system-scope release so that its stores have left this XCD's L2
 MM_DEVICE void gemm_publish(const GemmArgs& g, int wave) {

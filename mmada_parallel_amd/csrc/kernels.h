@@ -89,3 +89,6 @@ int launch_image_probs(const bf16_t* cond, const bf16_t* ut, const bf16_t* ui, i
 int launch_image_commit(int64_t* ids, int B, int L, const int32_t* pos_map, int N, const int32_t* sampled_in,
                         const bf16_t* p_in, const bf16_t* noise, float remask_temp, const int32_t* mask_len_sched,
                         int mask_id, int text_vocab, int codebook, int mvar, hipStream_t s);
+
+// probe.hip: MFMA-only diagnostic (attainable roof at the sustained clock on random data)
+int launch_mfma_probe(const bf16_t* data, float* sink, int iters, int launches, hipStream_t s, double* tflops_out, double* ms_out);

@@ -1,0 +1,77 @@
+// probe.hip — the attainable-MFMA probe behind mmada_mfma_probe (bench.py's `roofline.attainable_tflops`).
+//
+// Measurement only; nothing of the reference corresponds to it.  The dense bf16 peak of gfx950 (2.5 PFLOP/s) assumes the
+// 2.4 GHz engine clock; under a sustained MFMA load on RANDOM operands the part runs at its package power limit and
+// clocks lower (guide: DVFS give-back; zero-filled operands run ~20 % faster at equal cycles).  This kernel is what a
+// GEMM would be with every memory, LDS and barrier cost removed: eight waves per CU (two per SIMD, the occupancy of the
+// 8-phase GEMM) issue nothing but v_mfma_f32_16x16x32_bf16 — the production instruction — on operand fragments of
+// random bf16 data held in registers, 16 independent accumulators per wave.  Its rate, measured right after the timed
+// region of a bench run while the chip is still warm, is the roof a real kernel could at best approach on this part at
+// that moment; `roofline.frac` stays quoted against the 2.5 PFLOP/s datasheet peak.
+#include "kernels.h"
+
+namespace {
+
+constexpr int PROBE_WAVES = 8, PROBE_FRAGS = 4, MFMA_PER_ITER = PROBE_FRAGS * PROBE_FRAGS * 2;
+
+__global__ __launch_bounds__(PROBE_WAVES * 64, 2) void mfma_probe_kernel(const bf16_t* data, int iters, float* sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // 16 fragments (8 per operand) of this wave: 8 KiB of random bf16 per wave, different for every wave of the workgroup
+    const bf16x8* src = (const bf16x8*)data + (size_t)((blockIdx.x % 64) * PROBE_WAVES + wave) * 16 * 64 + lane;
+    bf16x8 a[2][PROBE_FRAGS], b[2][PROBE_FRAGS];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < PROBE_FRAGS; ++i) {
+            a[s][i] = src[(s * 8 + i) * 64];
+            b[s][i] = src[(s * 8 + 4 + i) * 64];
+        }
+    f32x4 acc[PROBE_FRAGS][PROBE_FRAGS];
+#pragma unroll
+    for (int i = 0; i < PROBE_FRAGS; ++i)
+#pragma unroll
+        for (int j = 0; j < PROBE_FRAGS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)  // two operand sets alternate, so consecutive MFMAs of a pipe see changing inputs
+#pragma unroll
+            for (int i = 0; i < PROBE_FRAGS; ++i)
+#pragma unroll
+                for (int j = 0; j < PROBE_FRAGS; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < PROBE_FRAGS; ++i)
+#pragma unroll
+        for (int j = 0; j < PROBE_FRAGS; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 123.456f) sink[0] = t;  // keeps the accumulators live; practically never true
+}
+
+}  // namespace
+
+// data: >= 64 * 8 * 16 * 64 * 16 bytes (8 MiB) of bf16 values the caller filled (random: never zeros — see above).
+// Runs `launches` back-to-back launches of `iters` iterations on `stream` and returns the achieved dense TFLOP/s.
+int launch_mfma_probe(const bf16_t* data, float* sink, int iters, int launches, hipStream_t s, double* tflops_out, double* ms_out) {
+    int dev = 0, cus = 0;
+    MM_CHECK_HIP(hipGetDevice(&dev));
+    MM_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    hipEvent_t e0, e1;
+    MM_CHECK_HIP(hipEventCreate(&e0));
+    MM_CHECK_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(cus), dim3(PROBE_WAVES * 64), 0, s, data, 64, sink);  // warm (code, clocks)
+    MM_CHECK_HIP(hipEventRecord(e0, s));
+    for (int i = 0; i < launches; ++i)
+        hipLaunchKernelGGL(mfma_probe_kernel, dim3(cus), dim3(PROBE_WAVES * 64), 0, s, data, iters, sink);
+    MM_CHECK_HIP(hipEventRecord(e1, s));
+    MM_CHECK_HIP(hipGetLastError());
+    MM_CHECK_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    MM_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    const double flops = (double)launches * cus * PROBE_WAVES * (double)iters * MFMA_PER_ITER * (2.0 * 16 * 16 * 32);
+    if (tflops_out) *tflops_out = flops / (ms * 1e-3) / 1e12;
+    if (ms_out) *ms_out = ms;
+    return 0;
+}
