@@ -1,13 +1,18 @@
 #!/usr/bin/env python
 """Headline benchmark: images/sec of the MMaDA-Parallel 8B parallel text+image sampler on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W [--config {1,3,4}]
+    python bench.py --gpus 1 --steps K --warmup W [--config {0,1,3,4}] [--scaling {weak,strong}]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 --config 1 (default, the headline): one "step" = one complete TI2TI job of BASELINE.json configs[1]: MMaDA-Parallel-A,
   512x512 output, text_steps=128, timesteps=64, cfg_scale=0, cfg_img=4.0, temperature=0, L = 2438 tokens, 256 forwards
   of the 8B denoiser (128 conditional + 64 x 2 unconditional).  With N GPUs the model is tensor-parallel over N ranks and
   the batch is N jobs (weak scaling, BASELINE configs[2]).
+--config 0: BASELINE configs[0], the reference's CPU-runnable plumbing case, on the GPU: 1 prompt, 256x256, text_steps=32,
+  timesteps=16, temperature=0, L = 1654, 64 forwards; the unmodified reference's end-to-end time for the same job
+  (tools/cpu_reference_baseline.py --end-to-end, build container) is attached to the line.
+--scaling strong (config 1): ONE job whatever the rank count (batch 1, tensor-parallel over all ranks) — the regime in which
+  every kernel shrinks with N while the launch count does not; use with --graph on.  Default: weak (batch = N jobs).
 --config 3: BASELINE configs[3] in its single-GPU form: MMaDA-Parallel-M (MAGVITv2 tokenizer), a batch of 4 edit jobs,
   each pixels in -> pixels out: MAGVITv2.get_code -> interleave_generate (text_steps 128, image_steps 30, text_cfg 2.5,
   image_cfg 4.0: 128 batch-2 forwards at L = 2349) -> decode_code.  One "step" = the 4 jobs.
@@ -28,6 +33,8 @@ sys.path.insert(0, ROOT)
 # the tensor-parallel exchange stream parks a (one-wave) wait kernel until the peers arrive: it must own a hardware queue,
 # not share one with the compute stream (the HIP runtime multiplexes streams over 4 queues by default)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# the bench records what BOTH transports deliver (config.allreduce_probe): connect RCCL next to the pull transport
+os.environ.setdefault("MMADA_TP_PROBE_RCCL", "1")
 
 import torch  # noqa: E402
 
@@ -128,11 +135,13 @@ def cpu_baseline(cfg, ids, text_rows, img_rows, seq_forwards, text_heads, img_he
            "sample": f"oracle/llada_oracle.py forward of {sample_layers} of {cfg['n_layers']} blocks + consumed LM-head "
                      f"rows at L={L} (best of {reps}), extrapolated to {seq_forwards} sequence-forwards/image: "
                      f"{per_forward:.2f} s/forward on {best_n} threads"}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r02_cpu_reference.json")) as f:
-            out["unmodified_reference_in_build_container"] = json.load(f)
-    except Exception:
-        pass
+    for key, fn in (("unmodified_reference_in_build_container", "r02_cpu_reference.json"),
+                    ("unmodified_reference_end_to_end_configs0", "r03_cpu_reference_e2e.json")):
+        try:
+            with open(os.path.join(ROOT, "profiles", fn)) as f:
+                out[key] = json.load(f)
+        except Exception:
+            pass
     return out
 
 
@@ -193,6 +202,37 @@ def measured_traffic(kernel):
         return None
 
 
+def traffic_ratios(kernel):
+    """Measured / algorithmic HBM-side bytes of the dominant kernel per launch shape (profiles/traffic.json)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        if t["kernel"] != kernel:
+            return {}
+        return {f"traffic_ratio_{k.lower()}": t["per_launch_bytes"][k] / t["algorithmic_bytes"][k] for k in t["per_launch_bytes"]}
+    except Exception:
+        return {}
+
+
+def attainable_probe(lib, dev, smi_index):
+    """~1 s of the library's MFMA-only kernel (mmada_mfma_probe: the production MFMA on register-resident RANDOM bf16
+    operands, no memory / LDS / barrier traffic) right after the timed region, while the part is as warm as the bench
+    left it: the rate a kernel could at best approach on THIS box at the clock it sustains, with the sclk / socket-power
+    medians of that second."""
+    from mmada_parallel_amd import abi
+
+    nbytes = lib.mmada_mfma_probe_bytes()
+    data = (torch.randn(nbytes // 2, device=dev) * 0.5).to(torch.bfloat16)
+    sink = torch.zeros(4, dtype=torch.float32, device=dev)
+    tf, ms = C.c_double(), C.c_double()
+    torch.cuda.synchronize()
+    with SmiSampler(smi_index) as smi:
+        abi.check(lib.mmada_mfma_probe(data.data_ptr(), sink.data_ptr(), 32768, 24, abi.stream_ptr(), C.byref(tf), C.byref(ms)),
+                  "mmada_mfma_probe")
+    return {"tflops": tf.value, "seconds": ms.value * 1e-3, "what": "v_mfma_f32_16x16x32_bf16 only, 8 waves/CU, random bf16 operands "
+            "in registers (mmada_mfma_probe), run right after the timed region", "rocm_smi": smi.summary()}
+
+
 def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
     """Returns a dict describing one benchmark step for BASELINE configs[cfgnum]: run(), images per step, FLOPs per image,
     the strings of the JSON line, and what the CPU baseline has to extrapolate to."""
@@ -207,20 +247,22 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
     def connect(model, max_batch, L):
         if tp > 1:
             model.init_tp_comm(max_batch=max_batch, max_len=L, transport=os.environ.get("MMADA_TP_TRANSPORT", "auto"))
-    if cfgnum in (1, 4):
+    if cfgnum in (0, 1, 4):
         from mmada_parallel_amd import LLaDAForMultiModalGeneration, generate_ti2ti
 
-        B = (tp if cfgnum == 1 else 16) if args.batch is None else args.batch
+        side = 256 if cfgnum == 0 else 512
+        B = ((1 if args.scaling == "strong" else tp) if cfgnum in (0, 1) else 16) if args.batch is None else args.batch
         cfg_scale = 0.0 if cfgnum == 1 else 3.0
         sd = synth.synthetic_state_dict(cfg, seed=0, device=str(dev))
         model = LLaDAForMultiModalGeneration.from_state_dict(full, sd, device=dev, tp_rank=rank if tp > 1 else 0,
                                                              tp_size=tp, max_batch=2 * B)
         del sd
         torch.cuda.empty_cache()
-        job = synth.synthetic_job(512, 512, text_gen_length=256, prompt_len=64, uncond_prompt_len=24, seed=1)
+        job = synth.synthetic_job(side, side, text_gen_length=256, prompt_len=64, uncond_prompt_len=24, seed=1)
         ids = job["input_ids"].repeat(B, 1).to(dev)
         L = ids.shape[1]
         T, N = job["text_end"] - job["text_start"], job["seq_len"]
+        grid = int(round(N ** 0.5))
         state = {}
         connect(model, 2 * B, L)
         # pixels in -> pixels out, as inference.py runs a job (:94-96,127,218-225): the input image is tokenised by the VQ
@@ -229,7 +271,7 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
         from mmada_parallel_amd import VQModel
 
         vq_model = VQModel.from_state_dict(synth.VQMODEL_CFG_A, synth.synthetic_vqmodel_state_dict(synth.VQMODEL_CFG_A, 2), device=dev)
-        pixels = ((synth.synthetic_image(B, 512, 512, seed=5) + 1.0) * 0.5).clamp(0, 1).to(dev)   # resident in HBM
+        pixels = ((synth.synthetic_image(B, side, side, seed=5) + 1.0) * 0.5).clamp(0, 1).to(dev)   # resident in HBM
         row = job["input_ids"][0]
         where = torch.arange(L)
         in_pos = ((row >= synth.TEXT_VOCAB) & (row < synth.TEXT_VOCAB + CB) & (where < job["image_start"])).nonzero()[:, 0].to(dev)
@@ -264,22 +306,53 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
                                           cfg_scale=cfg_scale, cfg_img=4.0, uncon_text=job["uncon_text"],
                                           uncon_image=job["uncon_image"], return_state=True)
             # decode_vq_to_image; the one position the schedule leaves masked is a random code in the reference (A.1)
-            out_codes = (final[mine][:, out_pos] - synth.TEXT_VOCAB).clamp(0, CB - 1).view(-1, 32, 32).to(dev)
+            out_codes = (final[mine][:, out_pos] - synth.TEXT_VOCAB).clamp(0, CB - 1).view(-1, grid, grid).to(dev)
             state["pixels"] = vq_model.decode(out_codes, force_not_quantize=True).sample.clip(0, 1)
             state["final"] = final
             return final
 
+        def launch_probe(graph):
+            """Host side of one image: time each step's ENQUEUE (next() of the step generator returns before the GPU has
+            run the step — the loop has no host sync) and the whole image's wall time, eager or hipGraph-replayed."""
+            from mmada_parallel_amd.generators.parallel_generator import _ti2ti_steps
+
+            gen = _ti2ti_steps(model, ids.clone(), job["text_start"], job["text_end"], job["image_start"], job["seq_len"],
+                               job["newline_every"], text_steps=args.text_steps, timesteps=args.timesteps, temperature=0.0,
+                               text_temperature=0.0, cfg_scale=cfg_scale, cfg_img=4.0, uncon_text=job["uncon_text"],
+                               uncon_image=job["uncon_image"], graph=graph)
+            host = {False: [], True: []}
+            torch.cuda.synchronize()
+            w0 = time.perf_counter()
+            while True:
+                t0 = time.perf_counter()
+                step, _, info = next(gen)
+                if step >= args.text_steps:
+                    break
+                host[bool(info["image_step"])].append(time.perf_counter() - t0)
+            torch.cuda.synchronize()
+            wall = time.perf_counter() - w0
+            med = lambda v: sorted(v)[len(v) // 2] * 1e3 if v else None
+            return {"wall_ms_per_image": wall * 1e3, "host_enqueue_ms_text_step_median": med(host[False]),
+                    "host_enqueue_ms_image_step_median": med(host[True]),
+                    "host_enqueue_ms_per_image": (sum(host[False]) + sum(host[True])) * 1e3,
+                    "graph_nodes_per_step_kind": {str(k): v for k, v in getattr(model, "graph_nodes", {}).items()} if graph else None}
+
         n_img = len(set(image_step_indices(args.text_steps, args.timesteps)))
         fl = job_flops(cfg, L, T, N, args.text_steps, n_img, V, CB, job if windowed else None)
-        name = ("BASELINE configs[1]: MMaDA-Parallel-A 8B, 512x512, timesteps=64, text_steps=128, cfg_img=4.0, "
-                "temperature=0, L=2438, 256 forwards/image, pixels in -> pixels out (VQ encode + decode inside the step)") \
+        name = ("BASELINE configs[0]: MMaDA-Parallel-A 8B, 1 prompt, 256x256, timesteps=16, text_steps=32, cfg_img=4.0, "
+                f"temperature=0, L={L}, 64 forwards/image (the reference's CPU-runnable case, here on the GPU), pixels in -> "
+                "pixels out") if cfgnum == 0 else \
+               ("BASELINE configs[1]: MMaDA-Parallel-A 8B, 512x512, timesteps=64, text_steps=128, cfg_img=4.0, "
+                "temperature=0, L=2438, 256 forwards/image, pixels in -> pixels out (VQ encode + decode inside the step)"
+                + (f"; STRONG scaling: one job over {tp} tensor-parallel rank(s)" if args.scaling == "strong" else "")) \
             if cfgnum == 1 else \
                (f"BASELINE configs[4] (single-GPU form): MMaDA-Parallel-A 8B editing, batch={B}, 512x512, cfg_scale=3.0 + "
                 "cfg_img=4.0 (triple-branch CFG), timesteps=64, text_steps=128, temperature=0, L=2438, 256 sequence-forwards/image")
-        metric = "images/sec (512x512, 64 img + 128 text steps) MMaDA-Parallel-A 8B" + \
+        metric = "images/sec (256x256, 16 img + 32 text steps) MMaDA-Parallel-A 8B" if cfgnum == 0 else \
+                 "images/sec (512x512, 64 img + 128 text steps) MMaDA-Parallel-A 8B" + \
                  ("" if cfgnum == 1 else ", editing mode, cfg_scale=3 + cfg_img=4")
         return dict(model=model, run=run, images_per_step=B, flops_per_image=fl, workload=name, metric=metric, L=L,
-                    state=state, cpu=dict(ids=job["input_ids"], text_rows=(job["text_start"], job["text_end"]),
+                    state=state, launch_probe=launch_probe, cpu=dict(ids=job["input_ids"], text_rows=(job["text_start"], job["text_end"]),
                                           img_rows=(job["image_start"], job["image_start"] + N),
                                           seq_forwards=args.text_steps + 2 * n_img, text_heads=args.text_steps, img_heads=3 * n_img))
     if cfgnum == 3:
@@ -343,7 +416,7 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
                     metric="images/sec (512x512 edit, 30 img + 128 text steps) MMaDA-Parallel-M 8B",
                     cpu=dict(ids=ids1, text_rows=(L - T, L), img_rows=(P + 1, P + 1 + N), seq_forwards=2 * args.text_steps,
                              text_heads=2 * args.text_steps, img_heads=2 * n_img))
-    raise SystemExit(f"--config {cfgnum}: only 1 (headline), 3 (M, batch 4) and 4 (A editing, batch 16) have a single-node form")
+    raise SystemExit(f"--config {cfgnum}: only 0, 1 (headline), 3 (M, batch 4) and 4 (A editing, batch 16) have a single-node form")
 
 
 def main():
@@ -351,11 +424,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", type=int, default=1, choices=[1, 3, 4],
+    ap.add_argument("--config", type=int, default=1, choices=[0, 1, 3, 4],
                     help="index into BASELINE.json configs (1 = the headline, the default the driver runs)")
     ap.add_argument("--batch", type=int, default=None, help="debug only: jobs per step (marks the line reduced)")
-    ap.add_argument("--text-steps", type=int, default=128, help="debug only: any other value marks the line reduced")
-    ap.add_argument("--timesteps", type=int, default=64, help="debug only")
+    ap.add_argument("--text-steps", type=int, default=None, help="debug only: any value other than the config's own "
+                    "(128; config 0: 32) marks the line reduced")
+    ap.add_argument("--timesteps", type=int, default=None, help="debug only (config's own: 64; config 0: 16)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="config 1 with N ranks: weak = N jobs per step (BASELINE configs[2]); strong = ONE job over all ranks")
+    ap.add_argument("--launch-probe", action="store_true",
+                    help="after the timed region: one image eager and one hipGraph-replayed with the host's per-step enqueue time "
+                         "(always on with --scaling strong)")
+    ap.add_argument("--no-probe", action="store_true", help="skip the ~1 s attainable-MFMA probe after the timed region")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (marks the line reduced)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
@@ -364,6 +444,9 @@ def main():
                     help="tp (default, BASELINE configs[2]): the model is tensor-parallel over all ranks, batch = N jobs; "
                          "dp: every rank holds the full 16 GB model and runs its own job, no data-path collective")
     args = ap.parse_args()
+    own_steps = (32, 16) if args.config == 0 else (128, 64)
+    args.text_steps = own_steps[0] if args.text_steps is None else args.text_steps
+    args.timesteps = own_steps[1] if args.timesteps is None else args.timesteps
     if args.graph != "auto":
         os.environ["MMADA_GRAPH"] = "1" if args.graph == "on" else "0"
 
@@ -398,7 +481,7 @@ def main():
     cfg = dict(synth.CFG_8B)
     if args.layers:
         cfg["n_layers"] = args.layers
-    reduced = (args.text_steps != 128 or args.timesteps != 64 or args.layers is not None or one_gpu
+    reduced = ((args.text_steps, args.timesteps) != own_steps or args.layers is not None or one_gpu
                or args.batch is not None)
     tp = world if args.parallelism == "tp" else 1
     wl = build_workload(args, args.config, None, dev, cfg, tp, world, rank)
@@ -438,6 +521,26 @@ def main():
     ar_probe = None
     if use_dist and tp > 1:
         ar_probe = model.collective_probe(L) if hasattr(model, "collective_probe") else None
+    comm_error = None
+    if getattr(model, "_comm_in_library", False):  # a hand-off of the pull transport timed out: the images are void
+        comm_error = model.comm_status()["error"]
+        if use_dist:
+            ce = torch.tensor([comm_error], device=dev, dtype=torch.int32)
+            dist.all_reduce(ce, op=dist.ReduceOp.MAX)
+            comm_error = int(ce.item())
+        if comm_error:
+            raise SystemExit(f"tensor-parallel exchange reported error {comm_error} (a peer never arrived): no benchmark line")
+    lprobe = None
+    if (args.launch_probe or args.scaling == "strong") and "launch_probe" in wl:
+        barrier()
+        lprobe = {"eager": wl["launch_probe"](False)}
+        barrier()
+        if model.graph_capturable():
+            lprobe["graph"] = wl["launch_probe"](True)
+        barrier()
+    probe = None
+    if rank == 0 and not args.no_probe:
+        probe = attainable_probe(lib, dev, local if not one_gpu else 0)
 
     if rank == 0:
         fl_img = wl["flops_per_image"]
@@ -454,7 +557,7 @@ def main():
             "metric": wl["metric"],
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak" if args.config == 1 else "strong", "vs_baseline": None,
+            "scaling": "weak" if args.config == 1 and args.scaling == "weak" else "strong", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": wl["workload"] + (" [REDUCED DEBUG RUN]" if reduced else ""),
                        "baseline_config_index": args.config,
@@ -464,7 +567,9 @@ def main():
                        "algorithmic_pflop_per_image": fl_img / 1e15,
                        "job_mfma_frac": value * fl_img / 1e12 / (world * MFMA_BF16_PEAK_TFLOPS),
                        "hipgraph_step": bool(getattr(model, "graph_replays", 0)),
+                       "hipgraph_nodes_per_step_kind": {str(k): v for k, v in getattr(model, "graph_nodes", {}).items()} or None,
                        "tp_ranks_agree": ranks_agree, "tp_collective": getattr(model, "tp_collective", None),
+                       "tp_comm_error": comm_error, "launch_probe": lprobe,
                        "allreduce_probe": ar_probe,
                        "rocm_smi_during_run": smi.summary() if smi else None,
                        "kernels": kinds},
@@ -474,6 +579,13 @@ def main():
                          "traffic_source": "profiles/traffic.json: separate rocprofv3 --pmc passes of a shortened "
                                            "(--text-steps 8 --timesteps 4) run of this command, not this run"},
         }
+        if args.config == 1:
+            out["roofline"].update(traffic_ratios(KIND_NAMES[dom]))
+        if probe:
+            out["roofline"].update({"attainable_tflops": probe["tflops"],
+                                    "frac_of_attainable": ach / probe["tflops"] if probe["tflops"] else None,
+                                    "job_frac_of_attainable": value * fl_img / 1e12 / (world * probe["tflops"]) if probe["tflops"] else None,
+                                    "attainable_probe": probe})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, **wl["cpu"])
         # native libraries (RCCL's version banner, gloo's connection notes) write to the C stdio buffer of fd 1, which is

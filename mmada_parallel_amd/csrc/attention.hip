@@ -228,10 +228,9 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     if (Lkv % 64 || Lkv < L) return mm_fail("attention: Lkv=%d must be a multiple of 64 and >= L=%d", Lkv, L);
     if (Hq % Hkv) return mm_fail("attention: n_heads %% n_kv_heads != 0");
     if (q_begin < 0 || (q_begin & 31) || q_begin >= Lq_rows) return mm_fail("attention: bad q_begin=%d", q_begin);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[16] = {};
+    if (mm_first_use_on_device(attr_set)) {
         MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
-        attr_set = true;
     }
     AttnArgs a;
     a.q = q; a.k = k; a.vT = vT; a.out = out;

@@ -66,3 +66,14 @@ MM_DEVICE int vt_key_pos(int l) {
     } while (0)
 
 int mm_fail(const char* fmt, ...);
+
+// Function attributes (the dynamic-LDS limit of a kernel) are per DEVICE: a process that drives several devices (the ranks of
+// a tensor-parallel group as handles of one process) must set them on each.  True the first time a launcher runs on the
+// current device; racing threads at worst set the same attribute twice.
+inline bool mm_first_use_on_device(bool (&seen)[16]) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return true;
+    if (seen[dev]) return false;
+    seen[dev] = true;
+    return true;
+}

@@ -160,7 +160,6 @@ int launch_cfg(const GemmArgs& g, hipStream_t s) {
     auto fn = gemm_bt_kernel<EPI, BM, WM, WN>;
     if (!attr_set) {
         MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        attr_set = true;
     }
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
     hipLaunchKernelGGL(fn, dim3(ntm * ntn), dim3(NTHREADS), LDS, s, g);

@@ -65,6 +65,17 @@ def mask_len_schedule(num_vq_tokens: int, text_steps: int, noise_schedule=cosine
     return out
 
 
+def check_tp_exchange(model):
+    """A hand-off of the tensor-parallel pull transport that timed out (a lost or stalled peer) sets a sticky device flag
+    and the ranks run on unsynchronised; nothing else would report it.  Called where the sampler synchronises anyway
+    (the read-out of the final ids): raises instead of returning an image computed from stale partial sums."""
+    if getattr(model, "_comm_in_library", False) and hasattr(model, "comm_status"):
+        st = model.comm_status()
+        if st["error"]:
+            raise abi.MmadaError(f"tensor-parallel exchange: hand-off timed out waiting for rank {st['error'] - 1} "
+                                 f"(transport {st['mode']}); the generated tokens are void")
+
+
 class TorchRng:
     """The reference's random draws, call for call, from torch's RNG on the tensors' device (:13-16, :30-33, :297-302).
     Parity tests pass an object with the same three methods that replays the draws of a recorded reference run."""
@@ -392,6 +403,7 @@ def generate_ti2ti(
 
     # ===== final read-out (reference :346-368) =====
     final_ids = ids.cpu()
+    check_tp_exchange(model)
     text_tokens = [t for t in final_ids[0, text_start:text_end].tolist() if t != MASK_TOKEN]
     generated_text = tokenizer.decode(text_tokens, skip_special_tokens=True) if tokenizer is not None else text_tokens
     image_tokens = []

@@ -484,18 +484,22 @@ class LLaDAForMultiModalGeneration:
             lib.mmada_comm_destroy(self._handle)
             chosen = "host all-reduce (torch.distributed)"
         self._rccl_also = False
-        if chosen == "pull" and os.environ.get("MMADA_TP_PROBE_RCCL", "1") == "1":
-            # one rank per device over RCCL as well: connect it too, so collective_probe() can time BOTH transports
+        if chosen == "pull" and os.environ.get("MMADA_TP_PROBE_RCCL", "0") == "1":
+            # OPT-IN (bench.py sets it): one rank per device over RCCL as well, so that collective_probe() can time BOTH
+            # transports.  A production start does not pay a second communicator (init time, memory, one more thing that
+            # can fail or hang at start-up).
             if all_agree(dist.get_backend(group) == "nccl"):
                 path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so").encode()
                 uid = C.create_string_buffer(128)
-                if self.tp_rank == 0:
-                    lib.mmada_comm_unique_id(uid, path)
-                box = [uid.raw]
+                uid_ok = self.tp_rank != 0 or lib.mmada_comm_unique_id(uid, path) == 0
+                box = [uid.raw if uid_ok else None]
                 dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-                ok = lib.mmada_comm_connect_rccl(self._handle, box[0], path) == 0   # leaves mode = RCCL
-                self._rccl_also = all_agree(ok)
-                lib.mmada_comm_set_mode(self._handle, 1)                             # the forward keeps the pull transport
+                if box[0] is not None:
+                    try:
+                        ok = lib.mmada_comm_connect_rccl(self._handle, box[0], path) == 0   # leaves mode = RCCL
+                    finally:
+                        lib.mmada_comm_set_mode(self._handle, 1)                         # the forward keeps the pull transport
+                    self._rccl_also = all_agree(ok)
         self.tp_collective = chosen
         return chosen
 
@@ -547,7 +551,10 @@ class LLaDAForMultiModalGeneration:
     def graph_capturable(self) -> bool:
         """True when forward_body / head_rows issue only stream launches (no host-side collective): the sampler may then
         capture a whole denoise step into one hipGraph (mmada_graph_*)."""
-        return self.tp_size == 1 or getattr(self, "_comm_in_library", False)
+        # RCCL's reduce-scatter / all-gather would be captured on a forked stream; whether every call it makes is
+        # capturable has never been exercised with more than one rank, so only the pull transport (plain kernels and
+        # device-memory counters) qualifies under tensor parallelism
+        return self.tp_size == 1 or (getattr(self, "_comm_in_library", False) and getattr(self, "tp_collective", None) == "pull")
 
     # ---- dLLM cache (model/modeling_llada.py:593-600,929-940,1244-1245,1406-1426) ----------------------------------------
     def caching(self, enable: bool = True):

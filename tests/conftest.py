@@ -4,7 +4,7 @@ import sys
 # tests/test_gpu_tp.py runs the ranks of a tensor-parallel group as handles of ONE process, each with its compute stream and
 # the library's exchange stream, and a rank's wait kernel spins until its peer's launches run: every stream needs a hardware
 # queue of its own (the HIP runtime multiplexes streams over 4 by default; read when the runtime initialises)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import pytest
 

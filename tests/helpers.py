@@ -266,6 +266,9 @@ def paint_util_image():
 
 
 # ---- in-process tensor-parallel rank groups (tests/test_gpu_tp.py, tests/test_gpu_parity_depth.py) ----
+_TP_STREAMS = []
+
+
 def tp_group(cfg_base, sd, tp, max_rows, dev="cuda:0"):
     """The ranks of a tensor-parallel group as separate handles of ONE process, each on its own stream, connected with
     mmada_comm_connect_local (tests/test_gpu_tp.py explains why this is the multi-device code path unchanged)."""
@@ -283,8 +286,12 @@ def tp_group(cfg_base, sd, tp, max_rows, dev="cuda:0"):
     for m in ranks:
         abi.check(lib.mmada_comm_connect_local(m._handle, arr), "connect_local")
         m._comm_in_library, m.tp_collective = True, "pull"
-    streams = [torch.cuda.Stream(device=dev) for _ in ranks]
-    return ranks, streams
+    # One pool of compute streams for every group this process ever builds: a rank's wait kernel spins until its peers'
+    # launches run, so no two live streams may share a hardware queue (GPU_MAX_HW_QUEUES, tests/conftest.py) — fresh
+    # streams per group would walk through the queues and end up doubling up (seen as hand-off timeouts, status.error).
+    while len(_TP_STREAMS) < tp:
+        _TP_STREAMS.append(torch.cuda.Stream(device=dev))
+    return ranks, _TP_STREAMS[:tp]
 
 
 def tp_each(ranks, streams, fn):

@@ -217,10 +217,11 @@ def test_full_depth_8b_forward_vs_oracle():
         hid = tp_each(ranks, streams, lambda m: m.hidden_state())
         tl = tp_each(ranks, streams, lambda m: m.head_rows(trow, 0, V))
         il = tp_each(ranks, streams, lambda m: m.head_rows(irow, synth.TEXT_VOCAB, synth.TEXT_VOCAB + synth.CODEBOOK))
+        for m in ranks:  # a timed-out hand-off (rig: two live streams on one hardware queue) voids everything below
+            assert m.comm_status()["error"] == 0, f"TP={tp} rank {m.tp_rank}: {m.comm_status()}"
         for r in range(1, tp):  # every rank holds the same all-gathered rows
-            assert torch.equal(hid[0], hid[r]) and torch.equal(tl[0], tl[r]) and torch.equal(il[0], il[r])
-        for m in ranks:
-            assert m.comm_status()["error"] == 0
+            assert torch.equal(hid[0], hid[r]), f"TP={tp}: residual stream of rank {r} differs from rank 0"
+            assert torch.equal(tl[0], tl[r]) and torch.equal(il[0], il[r]), f"TP={tp}: logits of rank {r} differ"
         tp_hip[tp] = (hid[0].cpu(), tl[0].cpu(), il[0].cpu())
         del ranks, streams, hid, tl, il
         torch.cuda.empty_cache()
