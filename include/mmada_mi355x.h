@@ -330,6 +330,15 @@ size_t mmada_vq_group_norm_scratch_bytes(int B);
 int mmada_profile_begin(mmada_handle* h, int layer);
 int mmada_profile_end(mmada_handle* h, int32_t* count_out /*[5]*/, double* ms_out /*[5]*/, double* flops_out /*[5]*/);
 
+/* ---- measurement / test switches (process-wide; no reference counterpart) --------------------------------------------
+ * Every choice below is between kernels that produce BIT-IDENTICAL results (tests/test_gpu_kernels.py); the switches exist
+ * so that sweeps and A/B tests can pin one.
+ *   "gemm_config"    -1 automatic (default: the cost model of csrc/gemm.hip); 0..3 the 8-phase kernel's tile configuration
+ *                    (320x256, 256x256, 160x256, 320x128); 1000 + BM the 16-wave kernel with that row-tile height
+ *   "attention_form" -1 automatic (default: MMADA_ATTN8 or 1); 0 the 4-wave kernel (two workgroups per CU); 1 the 8-wave
+ *                    ping-pong kernel */
+int mmada_set_option(const char* name, int value);
+
 /* ---- attainable-MFMA probe (bench.py's roofline.attainable_tflops; measurement only, no reference counterpart) -----
  * Runs `launches` launches of an MFMA-only kernel (v_mfma_f32_16x16x32_bf16 on register-resident operand fragments taken
  * from `data`, eight waves per CU, no memory / LDS / barrier traffic) on `stream`, synchronises, and returns the achieved

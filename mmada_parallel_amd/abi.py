@@ -71,6 +71,7 @@ SIGNATURES = {
     "mmada_lfq_gather": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "mmada_profile_begin": (c_int, [c_void_p, c_int]),
     "mmada_profile_end": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mmada_set_option": (c_int, [C.c_char_p, c_int]),
     "mmada_mfma_probe_bytes": (c_size_t, []),
     "mmada_mfma_probe": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "mmada_gemm_bt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

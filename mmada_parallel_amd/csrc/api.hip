@@ -11,6 +11,7 @@
 
 #include "../../include/mmada_mi355x.h"
 #include "handle.h"
+#include "gemm_epilogue.h"
 
 static thread_local char g_err[1024] = "";
 
@@ -295,6 +296,13 @@ int mmada_profile_end(mmada_handle* h, int32_t* count_out, double* ms_out, doubl
     h->prof.clear();
     h->prof_layer = -1;
     return 0;
+}
+
+int mmada_set_option(const char* name, int value) {
+    if (!name) return mm_fail("mmada_set_option: null name");
+    if (!strcmp(name, "gemm_config")) { gemm_force_config(value); return 0; }
+    if (!strcmp(name, "attention_form")) { attention_force_form(value); return 0; }
+    return mm_fail("mmada_set_option: unknown option '%s'", name);
 }
 
 size_t mmada_mfma_probe_bytes(void) { return (size_t)64 * 8 * 16 * 64 * 16; }

@@ -99,7 +99,59 @@ def test_rmsnorm(rows, d):
     assert (bits(out) != bits(ref)).float().mean() < 5e-3
 
 
+# ------------------------------------------------------------------------------------------------- GEMM configurations
+@pytest.mark.parametrize("M,N,K", [(2440, 1536, 512), (648, 1024, 1024), (8, 256, 256), (4880, 512, 4096), (328, 8200, 256)])
+def test_gemm_configurations_are_bit_identical(M, N, K):
+    """Every tile configuration of both GEMM kernels (8-phase: 320x256, 256x256, 160x256, 320x128 with swapped MFMA operand
+    roles and 8-byte epilogue accesses; 16-wave: BM 128..320) accumulates a K-tile at a time in the same order with the same
+    MFMA: the planner's choice never changes a bit of the result.  Ragged last tiles in M and N included."""
+    lib = abi.lib()
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
+    W = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).to(DEV)
+    outs = {}
+    try:
+        for code in (-1, 0, 1, 2, 3, 1128, 1160, 1192, 1224, 1256, 1320):
+            abi.check(lib.mmada_set_option(b"gemm_config", code), "set_option")
+            Cc = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+            abi.check(lib.mmada_gemm_bt(A.data_ptr(), W.data_ptr(), Cc.data_ptr(), M, N, K, st()), "gemm")
+            torch.cuda.synchronize()
+            outs[code] = Cc
+    finally:
+        lib.mmada_set_option(b"gemm_config", -1)
+    ref = (A.float() @ W.float().t())
+    assert ((outs[-1].float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-2).all()
+    for code, Cc in outs.items():
+        assert torch.equal(Cc, outs[-1]), f"configuration {code}: {int((Cc != outs[-1]).sum())} elements differ"
+
+
 # ----------------------------------------------------------------------------------------------------------- attention
+@pytest.mark.parametrize("B,H,Hkv,L", [(1, 2, 2, 70), (2, 2, 1, 333), (1, 8, 8, 1000), (1, 2, 2, 64), (1, 1, 1, 1), (1, 8, 8, 2438),
+                                       (2, 8, 4, 2438), (1, 2, 2, 129), (1, 2, 2, 192)])
+def test_attention_forms_are_bit_identical(handle, B, H, Hkv, L):
+    """The 8-wave ping-pong kernel (round 3: one workgroup of 256 queries per CU, the two wave groups one barrier apart, 3-slot
+    K / vT rings) does per wave exactly the arithmetic of the 4-wave kernel, in the same order: identical bits, for every
+    key-tile count (1, 2, 3 tiles exercise the guarded first / last iterations; 39 tiles the pinned steady state)."""
+    torch.manual_seed(1000 + L)
+    q = torch.randn(B, H, L, 128).to(torch.bfloat16).to(DEV)
+    k = torch.randn(B, Hkv, L, 128).to(torch.bfloat16).to(DEV)
+    v = torch.randn(B, Hkv, L, 128).to(torch.bfloat16).to(DEV)
+    k[0, 0, L // 2] *= 6.0   # a spike: forces the deferred-rescale branch in some rows (guide rule 26)
+    outs = []
+    lib = abi.lib()
+    try:
+        for form in (0, 1):
+            abi.check(lib.mmada_set_option(b"attention_form", form), "set_option")
+            out = torch.full((B, L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+            abi.check(lib.mmada_sdpa(handle, q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Hkv, L, st()), "sdpa")
+            torch.cuda.synchronize()
+            outs.append(out)
+    finally:
+        lib.mmada_set_option(b"attention_form", -1)
+    assert torch.isfinite(outs[1].float()).all()
+    assert torch.equal(outs[0], outs[1]), f"{int((outs[0] != outs[1]).sum())} elements differ"
+
+
 @pytest.mark.parametrize("B,H,Hkv,L", [(1, 2, 2, 70), (2, 2, 1, 333), (1, 4, 4, 1000), (1, 2, 2, 64), (1, 1, 1, 1),
                                        (1, 2, 2, 2438)])
 def test_sdpa(handle, B, H, Hkv, L):
