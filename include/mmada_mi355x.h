@@ -335,8 +335,8 @@ int mmada_profile_end(mmada_handle* h, int32_t* count_out /*[5]*/, double* ms_ou
  * so that sweeps and A/B tests can pin one.
  *   "gemm_config"    -1 automatic (default: the cost model of csrc/gemm.hip); 0..3 the 8-phase kernel's tile configuration
  *                    (320x256, 256x256, 160x256, 320x128); 1000 + BM the 16-wave kernel with that row-tile height
- *   "attention_form" -1 automatic (default: MMADA_ATTN8 or 1); 0 the 4-wave kernel (two workgroups per CU); 1 the 8-wave
- *                    ping-pong kernel */
+ *   "attention_form" -1 automatic (default: MMADA_ATTN_FORM or 1); 0 the round-2 issue order; 1 software-pipelined matrix
+ *                    blocks (fragments prefetched in registers, pinned issue order) */
 int mmada_set_option(const char* name, int value);
 
 /* ---- attainable-MFMA probe (bench.py's roofline.attainable_tflops; measurement only, no reference counterpart) -----

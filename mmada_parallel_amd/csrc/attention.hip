@@ -190,18 +190,18 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
                 pb[1][s2][j] = (__bf16)s1[8 * s2 + j];
             }
 
-        // ---- O^T += V^T · P^T ----
+        // ---- O^T += V^T · P^T ----  (the four accumulators interleaved: consecutive MFMAs never wait for each other; each
+        // accumulator still takes its key fragments in the order (t, s2) = (0,0) (0,1) (1,0) (1,1): bit-identical sums)
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-            const char* vrow = Vt + (db * 32 + ql) * 128;  // swizzle of row db*32+ql does not depend on db
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
+                for (int db = 0; db < 4; ++db) {
+                    const char* vrow = Vt + (db * 32 + ql) * 128;  // swizzle of row db*32+ql does not depend on db
                     const bf16x8 va = *(const bf16x8*)(vrow + (((4 * t + 2 * s2 + hi) ^ vsw) << 4));
                     o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, pb[t][s2], o[db], 0, 0, 0);
                 }
-        }
     }
 
     // ---- normalise and store: lane holds O[q_row][d = db*32 + 8g + 4hi + j] ----
@@ -221,24 +221,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
 }
 
-// ---- 8-wave "ping-pong" form (round 3) -----------------------------------------------------------------------------
-// Same arithmetic per wave, in the same order, as attn_fwd_kernel (bit-identical output), scheduled the way the 8-phase
-// GEMM is: ONE workgroup of eight waves = 256 query rows per CU; waves 0-3 and waves 4-7 (one of each on every SIMD) run
-// one barrier apart.  A wave's key-tile iteration is two barrier-separated phases
-//     A_i : matrix block   S(i) = K(i)·Q^T  (16 MFMA)  +  O += V(i-1)^T·P(i-1)  (16 MFMA)     ~1024 MFMA cycles
-//     B_i : soft-max of tile i (row max, rescale decision, 32 exp2, P -> bf16)                ~900 VALU cycles
-// so while one wave of a SIMD streams MFMAs its partner does the VALU / transcendental work of its soft-max — the matrix
-// pipe and the vector ALU of a SIMD are separate pipes — instead of the two meeting in the same phase by chance, as the two
-// independent 4-wave workgroups of a CU did (a wave spent ~1000 of ~3400 cycles per tile parked at the tile barrier,
-// profiles/r02_pmc_sq_model.txt).  K / vT tiles live in two 3-slot LDS rings (96 KiB) shared by all eight waves; a wave issues
-// its LDS-DMA pieces of K(i+2) and vT(i+1) at the top of A_i and retires the previous iteration's pieces with a COUNTED
-// vmcnt before the barrier that ends A_i, so every piece has a whole iteration (two phases) to land.
-//   RAW: K(i+1) / vT(i) are first read in A_(i+1) of the early group, i.e. after the barrier that ends the late group's A_i;
-//   WAR: slot (i+2) % 3 held K(i-1), last read in the late group's A_(i-1), which ended at least one barrier before the
-//        early group's A_i — and a ds_read of a phase has completed when the phase's MFMAs that consume it have issued.
-constexpr int QB8 = 256, NS8 = 3;
-constexpr int ATT8_LDS = 2 * NS8 * TILE_BYTES;
-
 // The kernel owns its whole LDS allocation and has no static __shared__ object: the dynamic segment starts at LDS address 0
 // (tests/test_isa.py), so LDS addresses are plain integers — no "base + offset" VALU add per access.
 typedef __attribute__((address_space(3))) const bf16x8* lds_frag_ptr;
@@ -250,18 +232,18 @@ MM_DEVICE lptr_t lds_at(int byte_off) { return (lptr_t)(uint32_t)byte_off; }
 #pragma clang diagnostic pop
 
 #define A8_SB() __builtin_amdgcn_sched_barrier(0)
-#define A8_BARRIER()                            \
-    do {                                        \
-        A8_SB();                                \
-        asm volatile("s_barrier" ::: "memory"); \
-        A8_SB();                                \
-    } while (0)
 
-__global__ __launch_bounds__(512, 2) void attn8_fwd_kernel(AttnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// ---- 4-wave kernel, pipelined matrix blocks (round 3) ---------------------------------------------------------------
+// The arithmetic and its order are those of attn_fwd_kernel (bit-identical output); what changes is how the two matrix
+// blocks of a key tile are issued.  hipcc scheduled them as  { 2 x ds_read_b128 ; s_waitcnt lgkmcnt(0) ; 2 x MFMA } x 8:
+// every step exposed an LDS round trip in front of 64 cycles of MFMA work.  Here the fragments run THREE k-steps (S) / four
+// MFMAs (PV) ahead of their use in registers, the order is pinned with sched_group_barrier, LDS addresses are per-lane
+// offsets + immediates (the two ring stages are compile-time constants: loop unrolled by two), the four O accumulators
+// are interleaved, and the eight LDS-DMA pieces of the next tile are issued one per MFMA pair inside the S block instead
+// of in one burst in front of it.
+__global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;  // 0: early group, 1: one barrier behind
     const int ql = lane & 31, hi = lane >> 5;
     int qb, h, b;
     if (a.xcd_pairs > 0) {
@@ -278,152 +260,92 @@ __global__ __launch_bounds__(512, 2) void attn8_fwd_kernel(AttnArgs a) {
     const bf16_t* Kp = a.k + (size_t)(b * a.Hkv + hkv) * a.Lkv * 128;
     const bf16_t* Vp = a.vT + (size_t)(b * a.Hkv + hkv) * 128 * a.Lkv;
 
-    const int q_row = a.q_begin + qb * QB8 + wave * 32 + ql;
+    const int q_row = a.q_begin + qb * QB + wave * 32 + ql;
     const int q_ld = min(q_row, a.Lq_alloc - 1);
     bf16x8 qf[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) qf[s] = *(const bf16x8*)(Qp + (size_t)q_ld * 128 + s * 16 + hi * 8);
-
     f32x16 o[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-    float m_run = -1e30f, l_run = 0.f;  // m_run in scaled log2 units
+    float m_run = -1e30f, l_run = 0.f;
 
-    // LDS-DMA: wave w moves K pieces 2w, 2w+1 (4 rows x 256 B each) and vT pieces 2w, 2w+1 (8 rows x 128 B)
-    unsigned koff[2], voff[2];
+    unsigned koff[4], voff[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int kr = (wave * 2 + i) * 4 + (lane >> 4);
+    for (int i = 0; i < 4; ++i) {
+        const int kr = (wave * 4 + i) * 4 + (lane >> 4);
         koff[i] = (unsigned)(kr * 128 + (((lane & 15) ^ (kr & 15)) << 3)) * 2u;
-        const int d = (wave * 2 + i) * 8 + (lane >> 3);
+        const int d = (wave * 4 + i) * 8 + (lane >> 3);
         voff[i] = (unsigned)(d * a.Lkv + (((lane & 7) ^ ((d >> 1) & 7)) << 3)) * 2u;
     }
-    // The ring slot of a tile is its index mod 3; the loop below is unrolled by three so that every slot is a
-    // compile-time constant and every LDS address is a precomputed per-lane offset plus an immediate (no VALU address
-    // arithmetic inside the matrix block: the partner wave of the SIMD is doing its soft-max on the same vector ALU).
-    auto stage_k = [&](auto slot_, int kt) {
-        constexpr int SLOT = decltype(slot_)::value;
+    auto stage = [&](auto buf_, int kt) {  // stage BUF: K at BUF * 32 KiB, vT 16 KiB behind it (the layout of attn_fwd_kernel)
+        constexpr int BUF = decltype(buf_)::value;
         const char* kb = (const char*)Kp + (size_t)kt * KB * 256;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            unsigned off = koff[i];
-            asm volatile("" : "+s"(kb), "+v"(off));  // scalar base + 32-bit lane offset, zero-extended here: saddr form
-            __builtin_amdgcn_global_load_lds((gptr_t)(kb + off), lds_at(SLOT * TILE_BYTES + wave * 2048 + i * 1024), 16, 0, 0);
-        }
-    };
-    auto stage_v = [&](auto slot_, int kt) {
-        constexpr int SLOT = decltype(slot_)::value;
         const char* vb = (const char*)Vp + (size_t)kt * KB * 2;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 4; ++i) {
+            unsigned off = koff[i];
+            asm volatile("" : "+s"(kb), "+v"(off));
+            __builtin_amdgcn_global_load_lds((gptr_t)(kb + off), lds_at(BUF * 2 * TILE_BYTES + wave * 4096 + i * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             unsigned off = voff[i];
             asm volatile("" : "+s"(vb), "+v"(off));
-            __builtin_amdgcn_global_load_lds((gptr_t)(vb + off), lds_at((NS8 + SLOT) * TILE_BYTES + wave * 2048 + i * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(vb + off), lds_at(BUF * 2 * TILE_BYTES + TILE_BYTES + wave * 4096 + i * 1024), 16, 0, 0);
         }
     };
-    // per-lane LDS read offsets: K fragment of k-step s (keys ql / 32+ql: + 8192), vT fragment (t, s2) of feature block db (+ db*4096)
     int kro[8], vro[4];
     {
         const int ksw = ql & 15, vsw = (ql >> 1) & 7;
 #pragma unroll
         for (int s = 0; s < 8; ++s) kro[s] = ql * 256 + (((2 * s + hi) ^ ksw) << 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) vro[j] = NS8 * TILE_BYTES + ql * 128 + (((2 * j + hi) ^ vsw) << 4);  // j = 2*t + s2
+        for (int j = 0; j < 4; ++j) vro[j] = TILE_BYTES + ql * 128 + (((2 * j + hi) ^ vsw) << 4);
     }
-
     const int nkt = (a.L + KB - 1) / KB;
-    stage_k(std::integral_constant<int, 0>{}, 0);
-    if (nkt > 1) stage_k(std::integral_constant<int, 1>{}, 1);
-    stage_v(std::integral_constant<int, 0>{}, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    A8_BARRIER();
-    if (grp == 1) A8_BARRIER();  // waves 4-7 run one barrier behind waves 0-3
+    stage(std::integral_constant<int, 0>{}, 0);
 
-    f32x16 s0, s1;
-    bf16x8 pb[2][2];
-    // One key-tile iteration; R = i % 3.  FULL: 1 <= i and i + 2 < nkt — nothing is conditional and the matrix block is one
-    // basic block whose issue order is pinned (sched_group_barrier); otherwise the guarded form for the first iteration
-    // and the last three.  Returns true after the last matrix block (i == nkt).
-    auto iteration = [&](auto r_, auto full_, int i) -> bool {
-        constexpr int R = decltype(r_)::value;
-        constexpr bool FULL = decltype(full_)::value;
-        constexpr int KS = R * TILE_BYTES, VS = ((R + 2) % 3) * TILE_BYTES;  // slots read: K(i), vT(i-1)
-        using KNext = std::integral_constant<int, (R + 2) % 3>;              // slots written: K(i+2), vT(i+1)
-        using VNext = std::integral_constant<int, (R + 1) % 3>;
-        // the read offsets are "redefined" here (no instruction): otherwise loop-invariant code motion materialises every
-        // offset + slot constant of the three unrolled iterations in a register of its own (seen: 100 spilled registers);
-        // like this each access is offset register + immediate
+    auto tile = [&](auto r_, int kt) {
+        constexpr int R = decltype(r_)::value, BASE = R * 2 * TILE_BYTES;
+        using Next = std::integral_constant<int, R ^ 1>;
         asm volatile("" : "+v"(kro[0]), "+v"(kro[1]), "+v"(kro[2]), "+v"(kro[3]), "+v"(kro[4]), "+v"(kro[5]), "+v"(kro[6]), "+v"(kro[7]));
         asm volatile("" : "+v"(vro[0]), "+v"(vro[1]), "+v"(vro[2]), "+v"(vro[3]));
-        // ======== A_i: matrix block — fragments are fetched three k-steps / four MFMAs ahead of their use ========
-        const bool do_s = FULL || i < nkt, do_pv = FULL || i > 0;
-        bf16x8 ka[3][2], va[4];
-        if (do_s) {
-#pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                ka[s][0] = lds_frag(kro[s] + KS);
-                ka[s][1] = lds_frag(kro[s] + KS + 8192);
-            }
-        }
-        int issued = 0;
-        if (FULL || i + 2 < nkt) { stage_k(KNext{}, i + 2); issued += 2; }
-        if (FULL || i + 1 < nkt) { stage_v(VNext{}, i + 1); issued += 2; }
-        if (do_s) {  // S^T = K(i) · Q^T for keys [0,32) and [32,64) of the tile
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s % 3][0], qf[s], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s % 3][1], qf[s], s1, 0, 0, 0);
-                if (s + 3 < 8) {
-                    ka[s % 3][0] = lds_frag(kro[s + 3] + KS);
-                    ka[s % 3][1] = lds_frag(kro[s + 3] + KS + 8192);
-                } else if (do_pv && s < 7) {  // the first vT fragments, while the last S MFMAs run
-                    va[2 * (s - 5)] = lds_frag(vro[2 * (s - 5)] + VS);
-                    va[2 * (s - 5) + 1] = lds_frag(vro[2 * (s - 5) + 1] + VS);
-                }
-            }
-        } else if (do_pv) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) va[j] = lds_frag(vro[j] + VS);
-        }
-        if (do_pv) {  // O^T += V(i-1)^T · P(i-1)^T : MFMA n = db*4 + j uses fragment j = 2*t + s2 of feature block db
-#pragma unroll
-            for (int n = 0; n < 16; ++n) {
-                const int db = n >> 2, j = n & 3;
-                o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[j], pb[j >> 1][j & 1], o[db], 0, 0, 0);
-                if (n + 4 < 16) va[j] = lds_frag(vro[j] + VS + (db + 1) * 4096);
-            }
-        }
-        if (FULL) {  // pin the issue order of the block: reads run ahead of the MFMAs that consume them
-            __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // K fragments of k-steps 0-2
-            __builtin_amdgcn_sched_group_barrier(0x020, 4, 0);   // the four LDS-DMA pieces
-#pragma unroll
-            for (int s = 0; s < 7; ++s) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-#pragma unroll
-            for (int n = 0; n < 12; ++n) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-        }
-        // the pieces this wave issued in the PREVIOUS iteration (K(i+1), vT(i)) have landed; this iteration's stay in flight
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         A8_SB();
-        if (issued == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (issued == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        A8_BARRIER();
-        if (!FULL && i == nkt) return true;
-
-        // ======== B_i: online soft-max of tile i (fp32, log2 domain); lane and lane^32 share a query ========
-        if (!FULL && i * KB + KB > a.L) {  // keys past L (only in the last tile) get -inf; select, so garbage K rows cannot leak NaN
-            const int kbase = i * KB + 4 * hi;
+        const bool more = kt + 1 < nkt;
+        // ---- S^T = K · Q^T ----
+        bf16x8 ka[3][2];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            ka[s][0] = lds_frag(kro[s] + BASE);
+            ka[s][1] = lds_frag(kro[s] + BASE + 8192);
+        }
+        if (more) stage(Next{}, kt + 1);
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s % 3][0], qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s % 3][1], qf[s], s1, 0, 0, 0);
+            if (s + 3 < 8) {
+                ka[s % 3][0] = lds_frag(kro[s + 3] + BASE);
+                ka[s % 3][1] = lds_frag(kro[s + 3] + BASE + 8192);
+            }
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (s + 3 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one LDS-DMA piece of the next tile (none in the last tile)
+        }
+        A8_SB();
+        if (kt * KB + KB > a.L) {
+            const int kbase = kt * KB + 4 * hi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kbase + (r & 3) + 8 * (r >> 2);
@@ -439,7 +361,7 @@ __global__ __launch_bounds__(512, 2) void attn8_fwd_kernel(AttnArgs a) {
         }
         float mx = fmax_nc(mxa, mxb);
         mx = fmax_nc(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2e;
-        if (!__all(mx - m_run <= DEFER_LOG2)) {  // wave-uniform: rescale only when some row's max really grew
+        if (!__all(mx - m_run <= DEFER_LOG2)) {
             const float m_new = fmax_nc(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             l_run *= alpha;
@@ -457,6 +379,7 @@ __global__ __launch_bounds__(512, 2) void attn8_fwd_kernel(AttnArgs a) {
             psum += s0[r] + s1[r];
         }
         l_run += psum;
+        bf16x8 pb[2][2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
@@ -464,25 +387,33 @@ __global__ __launch_bounds__(512, 2) void attn8_fwd_kernel(AttnArgs a) {
                 pb[0][s2][j] = (__bf16)s0[8 * s2 + j];
                 pb[1][s2][j] = (__bf16)s1[8 * s2 + j];
             }
-        A8_BARRIER();
-        return false;
+        A8_SB();
+        // ---- O^T += V^T · P^T ----
+        bf16x8 va[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) va[db] = lds_frag(vro[0] + BASE + db * 4096);
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            const int j = n >> 2, db = n & 3;
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[db], pb[j >> 1][j & 1], o[db], 0, 0, 0);
+            if (n + 4 < 16) va[db] = lds_frag(vro[j + 1] + BASE + db * 4096);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
+#pragma unroll
+        for (int n = 0; n < 12; ++n) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+        A8_SB();
     };
-    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-    iteration(I0{}, std::false_type{}, 0);
-    int i = 1;
-    for (; i + 4 < nkt; i += 3) {  // i % 3 == 1 here; all three iterations have i + 2 < nkt
-        iteration(I1{}, std::true_type{}, i);
-        iteration(I2{}, std::true_type{}, i + 1);
-        iteration(I0{}, std::true_type{}, i + 2);
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+        tile(std::integral_constant<int, 0>{}, kt);
+        tile(std::integral_constant<int, 1>{}, kt + 1);
     }
-    for (;; i += 3) {              // the last (up to five) iterations, guarded
-        if (iteration(I1{}, std::false_type{}, i)) break;
-        if (iteration(I2{}, std::false_type{}, i + 1)) break;
-        if (iteration(I0{}, std::false_type{}, i + 2)) break;
-    }
-    if (grp == 0) A8_BARRIER();
+    if (kt < nkt) tile(std::integral_constant<int, 0>{}, kt);
 
-    // ---- normalise and store: lane holds O[q_row][d = db*32 + 8g + 4hi + j] ----
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     if (q_row < a.Lq_rows) {
@@ -501,8 +432,8 @@ __global__ __launch_bounds__(512, 2) void attn8_fwd_kernel(AttnArgs a) {
 
 }  // namespace
 
-static int g_attn_form = -1;  // -1: read MMADA_ATTN8 once
-void attention_force_form(int form) { g_attn_form = form; }  // -1: back to MMADA_ATTN8 / default  // measurement / test hook: 0 = 4-wave, 1 = 8-wave ping-pong
+static int g_attn_form = -1;  // -1: read MMADA_ATTN_FORM once
+void attention_force_form(int form) { g_attn_form = form; }  // -1: back to MMADA_ATTN_FORM / default  // measurement / test hook: 0 = round-2 issue order, 1 = pipelined matrix blocks
 
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int B, int Hq, int Hkv, int L,
                      int Lq_rows, int Lkv, int out_rows_per_batch, int ld_out, hipStream_t s, int q_begin, int Lq_alloc) {
@@ -524,28 +455,22 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     const int pairs = Hq * B;
     static const bool xcd_aware = [] { const char* e = getenv("MMADA_ATTN_XCD"); return !(e && e[0] == '0'); }();
     if (g_attn_form < 0) {
-        const char* e = getenv("MMADA_ATTN8");  // 0: the 4-wave kernel (two independent workgroups per CU); 1: 8-wave ping-pong
+        const char* e = getenv("MMADA_ATTN_FORM");  // 0: round-2 issue order; 1 (default): pipelined matrix blocks
         g_attn_form = e ? atoi(e) : 1;
     }
-    if (g_attn_form == 1) {
-        static bool attr8[16] = {};
-        if (mm_first_use_on_device(attr8))
-            MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn8_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT8_LDS));
-        const int nq = (Lq_rows - q_begin + QB8 - 1) / QB8;
-        a.nq = nq;
-        a.xcd_pairs = (xcd_aware && pairs % 8 == 0) ? pairs / 8 : 0;
-        if (a.xcd_pairs) hipLaunchKernelGGL(attn8_fwd_kernel, dim3(nq * pairs), dim3(512), ATT8_LDS, s, a);
-        else hipLaunchKernelGGL(attn8_fwd_kernel, dim3(nq, Hq, B), dim3(512), ATT8_LDS, s, a);
-        MM_CHECK_HIP(hipGetLastError());
-        return 0;
-    }
     const int nq = (Lq_rows - q_begin + QB - 1) / QB;
+    auto fn = g_attn_form == 1 ? attn4p_fwd_kernel : attn_fwd_kernel;
+    if (g_attn_form == 1) {
+        static bool attr4[16] = {};
+        if (mm_first_use_on_device(attr4))
+            MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
+    }
     if (xcd_aware && pairs % 8 == 0) {
         a.xcd_pairs = pairs / 8; a.nq = nq;
-        hipLaunchKernelGGL(attn_fwd_kernel, dim3(nq * pairs), dim3(256), ATT_LDS, s, a);
+        hipLaunchKernelGGL(fn, dim3(nq * pairs), dim3(256), ATT_LDS, s, a);
     } else {
         a.xcd_pairs = 0; a.nq = nq;
-        hipLaunchKernelGGL(attn_fwd_kernel, dim3(nq, Hq, B), dim3(256), ATT_LDS, s, a);
+        hipLaunchKernelGGL(fn, dim3(nq, Hq, B), dim3(256), ATT_LDS, s, a);
     }
     MM_CHECK_HIP(hipGetLastError());
     return 0;

@@ -76,7 +76,7 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
                      int Lq_rows, int Lkv, int out_row_stride_per_batch, int ld_out, hipStream_t s, int q_begin = 0,
                      int Lq_alloc = 0);
 
-void attention_force_form(int form);  // 0: 4-wave kernel, 1: 8-wave ping-pong kernel (default); tests compare the two
+void attention_force_form(int form);  // 0: round-2 issue order, 1: pipelined matrix blocks (default); tests compare the two
 
 // sampler.hip
 struct TextStat { float lmax; int32_t arg; double sum; };  // one rank's record of a text row (vocabulary-parallel head)

@@ -129,9 +129,9 @@ def test_gemm_configurations_are_bit_identical(M, N, K):
 @pytest.mark.parametrize("B,H,Hkv,L", [(1, 2, 2, 70), (2, 2, 1, 333), (1, 8, 8, 1000), (1, 2, 2, 64), (1, 1, 1, 1), (1, 8, 8, 2438),
                                        (2, 8, 4, 2438), (1, 2, 2, 129), (1, 2, 2, 192)])
 def test_attention_forms_are_bit_identical(handle, B, H, Hkv, L):
-    """The 8-wave ping-pong kernel (round 3: one workgroup of 256 queries per CU, the two wave groups one barrier apart, 3-slot
-    K / vT rings) does per wave exactly the arithmetic of the 4-wave kernel, in the same order: identical bits, for every
-    key-tile count (1, 2, 3 tiles exercise the guarded first / last iterations; 39 tiles the pinned steady state)."""
+    """The pipelined form of the attention kernel (round 3: fragments prefetched three k-steps ahead with a pinned issue order,
+    the four O accumulators interleaved, LDS-DMA pieces spread over the S block) does per wave exactly the arithmetic of the
+    round-2 kernel, in the same order: identical bits, for odd and even key-tile counts and a forced rescale."""
     torch.manual_seed(1000 + L)
     q = torch.randn(B, H, L, 128).to(torch.bfloat16).to(DEV)
     k = torch.randn(B, Hkv, L, 128).to(torch.bfloat16).to(DEV)

@@ -20,10 +20,10 @@ def test_gemm8_counted_waits_see_only_lds_dma():
         assert n_dma >= 20 and n_wait >= 12, (name, n_dma, n_wait)
 
 
-def test_attention_8wave_kernel_keeps_its_dma_queue_counted():
-    report, errors = isa_check.check_attn8()
+def test_attention_matrix_blocks_are_software_pipelined():
+    report, errors = isa_check.check_attention()
     assert not errors, "\n".join(errors)
-    assert report and report[0][1] >= 12 and report[0][2] >= 96
+    assert report and report[0][2] >= 64
 
 
 def test_tp_pull_transport_uses_16_byte_system_scope_loads():

@@ -57,7 +57,7 @@ def main():
     torch.cuda.synchronize()
     ms = {0: [], 1: []}
     for _ in range(args.rounds):   # the two kernel forms interleaved in rounds (same clock, same heat)
-        for form in (0, 1):        # 0: 4-wave kernel, two workgroups per CU; 1: 8-wave ping-pong kernel
+        for form in (0, 1):        # 0: round-2 issue order; 1: software-pipelined matrix blocks (the default)
             abi.check(lib.mmada_set_option(b"attention_form", form), "set_option")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -68,7 +68,7 @@ def main():
     lib.mmada_set_option(b"attention_form", -1)
     for form in (0, 1):
         t = sorted(ms[form])[len(ms[form]) // 2]
-        print(f"B={B} L={L} form {form} ({'8-wave ping-pong' if form else '4-wave, 2 workgroups/CU'}): median {t * 1e3:.1f} us per "
+        print(f"B={B} L={L} form {form} ({'pipelined matrix blocks' if form else 'round-2 issue order'}): median {t * 1e3:.1f} us per "
               f"mmada_sdpa call (incl. 3 layout kernels) = {flops / t / 1e9:.0f} TF lower bound over {args.rounds} rounds of {args.iters}")
     ref = torch.nn.functional.scaled_dot_product_attention(q[:, :2].float(), k[:, :2].float(), v[:, :2].float())
     got = out.view(B, L, H, 128)[:, :, :2].permute(0, 2, 1, 3).float()

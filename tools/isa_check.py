@@ -157,48 +157,31 @@ def check_gemm8(asm=None):
     return report, errors
 
 
-def check_attn8(asm=None):
-    """The 8-wave attention kernel: LDS-DMA behind counted waits like the GEMM (its main loop must hold no compiler-made
-    vmcnt(0) and no scratch access) and integer-formed LDS addresses (no static LDS)."""
+def check_attention(asm=None):
+    """The pipelined attention kernel: its matrix blocks must really be software-pipelined (counted lgkmcnt waits, not a
+    full drain in front of every MFMA pair), it forms LDS addresses from integers (no static LDS) and must not spill."""
     asm = asm or device_asm("attention.hip")
     body, meta = kernels(asm)
     report, errors = [], []
     for name, lines in body.items():
-        if "attn8_fwd_kernel" not in name:
+        if "attn4p_fwd_kernel" not in name:
             continue
         lds = int(meta.get(name, {}).get("group_segment_fixed_size", "0"))
         if lds != 0:
             errors.append(f"{name}: static LDS of {lds} bytes")
         n_scratch = sum(1 for ln in lines if re.match(r"\s*scratch_", ln))
         if n_scratch:
-            errors.append(f"{name}: {n_scratch} scratch accesses (register spills enter the vector-memory queue of the counted waits)")
-        # loop bodies: from a loop-header label to the last branch back to it
-        bad = 0
-        for i, ln in enumerate(lines):
-            m = re.match(r"^(\.LBB\w+):.*Inner Loop Header", ln)
-            if not m:
-                continue
-            back = [j for j in range(i, len(lines)) if re.match(r"\s*s_c?branch\w*\s+" + re.escape(m.group(1)) + r"\b", lines[j])]
-            if not back:
-                continue
-            in_asm = False
-            for ln2 in lines[i:back[-1]]:
-                s2 = ln2.strip()
-                if s2.startswith(";;#ASMSTART"):
-                    in_asm = True
-                elif s2.startswith(";;#ASMEND"):
-                    in_asm = False
-                elif not in_asm and re.match(r"s_waitcnt.*vmcnt\(0\)", s2):
-                    bad += 1
-        if bad:
-            errors.append(f"{name}: {bad} compiler-inserted vmcnt(0) waits inside a loop (the LDS-DMA queue is drained every iteration)")
+            errors.append(f"{name}: {n_scratch} scratch accesses (register spills)")
+        counted = sum(1 for ln in lines if re.match(r"\s*s_waitcnt lgkmcnt\([1-9]\d*\)", ln))
         n_dma = sum(1 for ln in lines if ln.strip().startswith("global_load_lds_dwordx4"))
         n_saddr = sum(1 for ln in lines if re.search(r"global_load_lds_dwordx4\s+v\d+,\s*s\[", ln))
         if n_dma == 0 or n_saddr != n_dma:
             errors.append(f"{name}: {n_saddr} of {n_dma} LDS-DMA loads use the scalar-base form")
-        report.append((name, n_dma, sum(1 for ln in lines if "v_mfma" in ln)))
+        if counted < 12:
+            errors.append(f"{name}: only {counted} counted lgkmcnt waits: the fragment prefetch was serialised by the compiler")
+        report.append((name, n_dma, sum(1 for ln in lines if "v_mfma" in ln), counted))
     if not report:
-        errors.append("no attn8 kernel found")
+        errors.append("attn4p kernel not found")
     return report, errors
 
 
@@ -230,9 +213,9 @@ def main():
     for name, n_dma, n_wait, n_foreign in rep:
         print(f"gemm8  {name[:90]:90s} LDS-DMA {n_dma:3d}  counted waits {n_wait:3d}  foreign VMEM after the first DMA {n_foreign}")
     bad += err
-    rep, err = check_attn8()
-    for name, n_dma, n_mfma in rep:
-        print(f"attn8  {name[:90]:90s} LDS-DMA {n_dma:3d}  MFMA {n_mfma}")
+    rep, err = check_attention()
+    for name, n_dma, n_mfma, counted in rep:
+        print(f"attn   {name[:90]:90s} LDS-DMA {n_dma:3d}  MFMA {n_mfma}  counted lgkmcnt waits {counted}")
     bad += err
     rep, err = check_tp_pull()
     for name, x4, x2 in rep:
