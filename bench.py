@@ -271,13 +271,14 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
         from mmada_parallel_amd import VQModel
 
         vq_model = VQModel.from_state_dict(synth.VQMODEL_CFG_A, synth.synthetic_vqmodel_state_dict(synth.VQMODEL_CFG_A, 2), device=dev)
-        pixels = ((synth.synthetic_image(B, side, side, seed=5) + 1.0) * 0.5).clamp(0, 1).to(dev)   # resident in HBM
+        pixels = ((synth.synthetic_image(B, 512, 512, seed=5) + 1.0) * 0.5).clamp(0, 1).to(dev)   # the INPUT image: 512x512 in every config
         row = job["input_ids"][0]
         where = torch.arange(L)
         in_pos = ((row >= synth.TEXT_VOCAB) & (row < synth.TEXT_VOCAB + CB) & (where < job["image_start"])).nonzero()[:, 0].to(dev)
         out_pos = torch.tensor([i for i in range(job["image_start"], job["image_start"] + N + N // job["newline_every"])
                                 if int(row[i]) != synth.NEW_LINE])  # generate_ti2ti hands the final ids back on the host
-        assert in_pos.numel() == N and out_pos.numel() == N
+        n_in = int(in_pos.numel())
+        assert n_in == 1024 and out_pos.numel() == N
 
         # tensor parallel: every rank needs every job's ids, but tokenising / decoding all B images on every rank would be
         # replicated work that does not shrink with the rank count — each rank handles its own slice of the jobs and the
@@ -286,16 +287,16 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
         mine = slice(rank * (B // tp), (rank + 1) * (B // tp)) if share else slice(0, B)
 
         def run():
-            codes = vq_model.quantize(vq_model.encode(pixels[mine]).latents)[2][2].view(-1, N)   # encode_img_with_breaks
+            codes = vq_model.quantize(vq_model.encode(pixels[mine]).latents)[2][2].view(-1, n_in)   # encode_img_with_breaks
             if share:
                 import torch.distributed as dist
 
                 if dist.get_backend() == "gloo":   # the one-GPU test rig: gloo gathers host tensors
-                    parts = [torch.empty((B // tp, N), dtype=codes.dtype) for _ in range(tp)]
+                    parts = [torch.empty((B // tp, n_in), dtype=codes.dtype) for _ in range(tp)]
                     dist.all_gather(parts, codes.cpu())
                     codes = torch.cat(parts, 0).to(dev)
                 else:
-                    allc = torch.empty((B, N), dtype=codes.dtype, device=dev)
+                    allc = torch.empty((B, n_in), dtype=codes.dtype, device=dev)
                     dist.all_gather_into_tensor(allc, codes.contiguous())
                     codes = allc
             job_ids = ids.clone()
