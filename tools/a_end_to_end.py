@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--prompt", default="Make the sky look like a watercolour painting at sunset.")
     ap.add_argument("--out", default=os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "a_e2e"))
     args = ap.parse_args()
+    if args.painting_mode and (args.height, args.width) != (512, 512):
+        ap.error("painting mode edits the 512x512 conditioning picture in place: the output grid is the input grid (inference.py:141-146)")
     from PIL import Image
 
     dev = "cuda:0"

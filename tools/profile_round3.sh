@@ -18,9 +18,10 @@ if has bench; then
 fi
 if has rig; then
   # strong scaling on the one-GPU rig: ONE job over 2 / 4 / 8 tensor-parallel processes sharing this GPU (hipIpc pull transport,
-  # gloo control plane), hipGraph on; the line carries the eager-vs-graph launch probe.  Not a throughput measurement.
+  # gloo control plane), hipGraph on; the line carries the eager-vs-graph launch probe.  Not a throughput measurement: the
+  # processes time-slice one device (an exchange costs 0.13 ms with 2 processes and ~100 ms with 8), hence the reduced depth.
   for n in 2 4 8; do
-    MMADA_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=$n --master-addr 127.0.0.1 --master-port 2966$n bench.py --gpus $n --steps 1 --warmup 1 --no-cpu-baseline --no-probe --scaling strong --graph on > $O/rig_strong_tp$n.json 2> $O/rig_strong_tp$n.err; echo "rig strong tp$n rc=$?"
+    MMADA_BENCH_ONE_GPU=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=$n --master-addr 127.0.0.1 --master-port 2966$n bench.py --gpus $n --steps 1 --warmup 1 --layers 4 --text-steps 16 --timesteps 8 --no-cpu-baseline --no-probe --scaling strong --graph on > $O/rig_strong_tp$n.json 2> $O/rig_strong_tp$n.err; echo "rig strong tp$n rc=$?"
   done
 fi
 if has prof; then
