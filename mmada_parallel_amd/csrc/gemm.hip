@@ -193,6 +193,9 @@ Plan plan(const GemmArgs& g) {
         if (!e && b) g_force = 1000 + atoi(b);
     }
     const bool can8 = gemm8_supports(g);
+#ifdef MMADA_TUNE
+    if (g_force >= 0 && g_force < GEMM8_NCFG + 5 && can8) return {true, g_force};
+#endif
     if (g_force >= 0 && g_force < GEMM8_NCFG && can8) return {true, g_force};
     if (g_force >= 1000) {
         const int bm = g_force - 1000;

@@ -64,9 +64,11 @@ MM_DEVICE void wait_vm() {
 // SW: operand roles of the MFMAs.  0: (activation, weight) — the C layout of gemm_epilogue;  1: swapped, the transposed C
 // layout of gemm_epilogue_t (a lane owns four consecutive columns of a row: 8-byte epilogue accesses);  2: chosen per wave
 // (`swap`): the QKV projection, whose V waves want the untransposed layout.  Same products, same k order: same bits.
-template <int BM_, int BN_, int WM_, int WN_, int SW_>
+// OPT (tuning builds only, tools/gemm_sweep.py): bit 0 = static s_setprio 1 for the late wave group; bit 1 = the phase's
+// ds_reads are issued before its LDS-DMA pieces.
+template <int BM_, int BN_, int WM_, int WN_, int SW_, int OPT_ = 0>
 struct Gemm8 {
-    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, SW = SW_;
+    static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, SW = SW_, OPT = OPT_;
     static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
     static constexpr int FA0 = (FM + 1) / 2, FA1 = FM / 2, FB = FN / 2;  // fragments of the A halves / of a W half
     static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES, LDS = 2 * STAGE;
@@ -196,23 +198,26 @@ struct Gemm8 {
     MM_DEVICE void tile(int kt) {
         constexpr int FOUR = NA0 + NA1 + 2 * NB;  // this wave's LDS-DMA instructions of four half-tiles
         // ---- P1: quadrant (A0, B0) ----
-        if (TAIL < 2) stage_w<B ^ 1, 1>(kt + 1);
+        if (!(OPT & 2) && TAIL < 2) stage_w<B ^ 1, 1>(kt + 1);
         read_a<B, 0>();
         read_b<B, 0>(bf0);
+        if ((OPT & 2) && TAIL < 2) stage_w<B ^ 1, 1>(kt + 1);
         if (TAIL < 2) wait_vm<FOUR>(); else wait_vm<NA1>();  // B1(kt) has landed
         G8_BARRIER();
         mma<0, 0, SWAP>(bf0);
         G8_BARRIER();
         // ---- P2: (A0, B1) ----
-        if (TAIL < 2) stage_a<B ^ 1, 1, NA1>(kt + 1);
+        if (!(OPT & 2) && TAIL < 2) stage_a<B ^ 1, 1, NA1>(kt + 1);
         read_b<B, 1>(bf1);
+        if ((OPT & 2) && TAIL < 2) stage_a<B ^ 1, 1, NA1>(kt + 1);
         if (TAIL < 2) wait_vm<FOUR>(); else wait_vm<0>();    // A1(kt) has landed
         G8_BARRIER();
         mma<0, 1, SWAP>(bf1);
         G8_BARRIER();
         // ---- P3: (A1, B1) ----
-        if (TAIL == 0) stage_a<B, 0, NA0>(kt + 2);
+        if (!(OPT & 2) && TAIL == 0) stage_a<B, 0, NA0>(kt + 2);
         read_a<B, 1>();
+        if ((OPT & 2) && TAIL == 0) stage_a<B, 0, NA0>(kt + 2);
         G8_BARRIER();
         mma<1, 1, SWAP>(bf1);
         G8_BARRIER();
@@ -235,6 +240,7 @@ struct Gemm8 {
         wait_vm<NA0 + NA1 + 2 * NB>();
         G8_BARRIER();
         if (grp == 1) G8_BARRIER();  // waves 4-7 run one barrier behind waves 0-3
+        if ((OPT & 1) && grp == 1) __builtin_amdgcn_s_setprio(1);
         for (int kt = 0; kt + 2 < nk; kt += 2) {
             tile<0, NA0, NA1, 0, SWAP>(kt);
             tile<1, NA0, NA1, 0, SWAP>(kt + 1);
@@ -299,6 +305,13 @@ int launch_epi8(int cfg, const GemmArgs& g, hipStream_t s) {
         case GEMM8_256x256: return launch_cfg8<EPI, Gemm8<256, 256, 2, 4, SW>>(g, s);
         case GEMM8_160x256: return launch_cfg8<EPI, Gemm8<160, 256, 2, 4, SW>>(g, s);
         case GEMM8_320x128: return launch_cfg8<EPI, Gemm8<320, 128, 4, 2, SW>>(g, s);
+#ifdef MMADA_TUNE
+        case 4: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 1>>(g, s);
+        case 5: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 2>>(g, s);
+        case 6: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 3>>(g, s);
+        case 7: return launch_cfg8<EPI, Gemm8<256, 256, 2, 4, SW, 2>>(g, s);
+        case 8: return launch_cfg8<EPI, Gemm8<160, 256, 2, 4, SW, 2>>(g, s);
+#endif
     }
     return mm_fail("gemm8: unknown configuration %d", cfg);
 }

@@ -17,7 +17,7 @@ def build(force=False):
     srcs = [os.path.join(HERE, "gemm_var.hip"), os.path.join(HERE, "gemm8.hip"), os.path.join(HERE, "tune_api.hip"), os.path.join(CSRC, "gemm.hip"), os.path.join(CSRC, "gemm8.hip")]
     if not force and os.path.exists(LIB) and all(os.path.getmtime(s) < os.path.getmtime(LIB) for s in srcs):
         return LIB
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-I", CSRC] + srcs + ["-o", LIB]
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMMADA_TUNE", "-I", CSRC] + srcs + ["-o", LIB]
     subprocess.run(cmd, check=True)
     return LIB
 
