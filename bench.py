@@ -53,7 +53,7 @@ def last_block_saving(cfg, L, lo, hi):
     """FLOPs the last block does not spend when only rows [lo, hi) are consumed (mmada_set_consumed_rows): attention
     queries, attn_out and the MLP run on the window (start rounded down to 32 rows); QKV still covers every row."""
     d, F = cfg["d_model"], cfg["mlp_hidden_size"]
-    w = hi - (lo & ~31)
+    w = ((hi + 7) & ~7) - (lo & ~31)   # start rounded down to the 32-query granule, end up to 8 rows
     if w >= L:
         return 0.0
     return (L - w) * (2.0 * (d * d + 3 * d * F) + 4.0 * L * d)

@@ -2,6 +2,7 @@
 // of one denoiser forward (embedding → n_layers × [RMSNorm → QKV+RoPE GEMM → flash attention → attn_out GEMM +
 // residual → RMSNorm → gate/up GEMM + SiLU·mul → down GEMM + residual] → RMSNorm → LM-head rows).
 // Host code only; every kernel lives in gemm.hip / attention.hip / elementwise.hip / sampler.hip.
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -211,12 +212,15 @@ int mmada_attn_partial(mmada_handle* h, int layer, void* stream) {
     }
     // last block + consumed-row window: only the rows the caller will read are attended / projected (bit-identical on
     // them: the window start is rounded down to the 32-query wave granule, so every wave sees the queries it saw before)
-    int wbeg = 0, W = 0;
+    // The window END is rounded up to a multiple of 8 rows (inside the Lp-padded stream): the compact panel then meets the
+    // shape contract of the 8-phase GEMM (whole 8-row LDS-DMA pieces); the up to 7 extra rows are computed like any other.
+    int wbeg = 0, wend = 0, W = 0;
     if (!cc && layer == h->cfg.n_layers - 1 && h->win_end > h->win_beg) {
         if (h->win_end > h->L) return mm_fail("forward: consumed rows [%d,%d) exceed L=%d", h->win_beg, h->win_end, h->L);
         wbeg = h->win_beg & ~31;
-        W = h->win_end - wbeg;
-        if (W >= h->L) { wbeg = 0; W = 0; }  // nothing to skip
+        wend = std::min((h->win_end + 7) & ~7, h->Lp);
+        W = wend - wbeg;
+        if (W >= h->Lp) { wbeg = 0; W = 0; }  // nothing to skip
     }
     const int Mo = W ? h->B * W : h->M;
     const double orows = W ? (double)h->B * W : rows;
@@ -226,7 +230,7 @@ int mmada_attn_partial(mmada_handle* h, int layer, void* stream) {
             if (launch_attention(h->q, g.k, g.vT, h->att, h->B, h->hq_l, h->hkv_l, cc->L, h->Lp, cc->Lkv, h->Lp,
                                  h->hq_l * 128, s, 0, h->Lkv)) return 1;
         } else if (W) {
-            if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->win_end, h->Lkv, W,
+            if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, wend, h->Lkv, W,
                                  h->hq_l * 128, s, wbeg)) return 1;
         } else if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->Lp, h->Lkv, h->Lp,
                                     h->hq_l * 128, s)) return 1;
