@@ -9,8 +9,9 @@
 //   * a K-tile is FOUR phases; a phase multiplies one quadrant of the wave tile: one A half (FA fragments x 2 k-steps, held
 //     in registers for two phases) against one W half (FB fragments x 2 k-steps):
 //         P1 (A0,B0)   P2 (A0,B1)   P3 (A1,B1)   P4 (A1,B0)
-//     phase = { LDS-DMA issue for a later K-tile ; ds_read_b128 of the operand half that changes ; counted vmcnt ; barrier ;
-//               MFMA cluster ; barrier }.
+//     phase = { LDS-DMA issue for a later K-tile ; ds_read_b128 of ONE operand half ; counted vmcnt ; barrier ;
+//               MFMA cluster ; barrier }.  P1 reads A0, P2 B1, P3 A1 and P4 the NEXT K-tile's B0 (into the W registers P3
+//     released), so no phase has to fetch two halves while its SIMD partner is only 20 MFMAs long.
 //   * the LDS image of a K-tile is cut the same way into four HALF-TILES (A0, A1, B0, B1 = the rows every wave reads for
 //     that half).  A half-tile slot is re-filled two phases after its last ds_read, with the data of the K-tile AFTER next:
 //     four half-tiles (one whole K-tile, up to 72 KiB per CU) are always in flight, each issued at least four phases — one
@@ -64,14 +65,17 @@ MM_DEVICE void wait_vm() {
 // SW: operand roles of the MFMAs.  0: (activation, weight) — the C layout of gemm_epilogue;  1: swapped, the transposed C
 // layout of gemm_epilogue_t (a lane owns four consecutive columns of a row: 8-byte epilogue accesses);  2: chosen per wave
 // (`swap`): the QKV projection, whose V waves want the untransposed layout.  Same products, same k order: same bits.
-// OPT (tuning builds only, tools/gemm_sweep.py): bit 0 = static s_setprio 1 for the late wave group; bit 1 = the phase's
-// ds_reads are issued before its LDS-DMA pieces.
+// OPT: bit 0 = static s_setprio 1 for the late wave group (tuning builds only, tools/gemm_sweep.py);  bit 1 = balanced
+// read schedule (tile_bal).
 template <int BM_, int BN_, int WM_, int WN_, int SW_, int OPT_ = 0>
 struct Gemm8 {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, SW = SW_, OPT = OPT_;
     static constexpr int TM = BM / WM, TN = BN / WN, FM = TM / 16, FN = TN / 16;
     static constexpr int FA0 = (FM + 1) / 2, FA1 = FM / 2, FB = FN / 2;  // fragments of the A halves / of a W half
-    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES, LDS = 2 * STAGE;
+    // LDS image: [A of buffer 0][A of buffer 1][W of buffer 0][W of buffer 1] — both buffers of an operand lie within the
+    // 16-bit immediate of ds_read_b128 from ONE per-lane base (two bases per operand, one per k-step)
+    static constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, W_BASE = 2 * A_BYTES, LDS = 2 * (A_BYTES + B_BYTES);
+    static_assert(A_BYTES + TM * 128 <= 65536 && B_BYTES + TN * 128 <= 65536, "second buffer within the ds_read immediate");
     // 1-KiB LDS-DMA pieces (8 rows x 128 B) per half-tile; wave w moves pieces w, w+8, w+16
     static constexpr int NPA0 = WM * FA0 * 2, NPA1 = WM * FA1 * 2, NPB = WN * FB * 2;
     static constexpr int RA0 = NPA0 % 8, RA1 = NPA1 % 8;  // waves below the remainder move one piece more
@@ -92,9 +96,9 @@ struct Gemm8 {
     unsigned arow[2][3], wrow[2][2];  // wave-uniform source byte offsets of this wave's pieces, [half][piece]
     bool azero[2][3];                 // piece lies wholly beyond M: stream zeros (the products are discarded either way,
                                       // but MFMAs on zeros switch far less — this workload runs at the power limit)
-    int alds[2][3], wlds[2][2];       // wave-uniform LDS byte offsets of those pieces inside a stage
-    int ra[2][2], rb[2][2];           // per-lane LDS read offsets [buffer][k-step] of fragment 0 (the rest are immediates;
-                                      // the second buffer's offsets exceed the 16-bit immediate range)
+    int alds[2][3], wlds[2][2];       // wave-uniform LDS byte offsets of those pieces in buffer 0
+    int ra[2], rb[2];                 // per-lane LDS read offsets [k-step] of fragment 0 in buffer 0 (the other fragments
+                                      // and the second buffer are immediates)
     bf16x8 af[FA0][2], bf0[FB][2], bf1[FB][2];
     f32x4 acc[FM][FN];
 
@@ -123,19 +127,16 @@ struct Gemm8 {
                 const int p = wave + 8 * i;
                 const int row0 = (p / (FB * 2)) * TN + h * FB * 16 + (p % (FB * 2)) * 8;
                 wrow[h][i] = (unsigned)min(row0, nrem - 8) * (unsigned)(g.ldw * 2);
-                wlds[h][i] = A_BYTES + row0 * 128;
+                wlds[h][i] = W_BASE + row0 * 128;
             }
         }
         const int frow = lane & 15, fq = lane >> 4, sw = (frow >> 1) & 7;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             const int lanepart = frow * 128 + (((kk * 4 + fq) ^ sw) << 4);
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                ra[b][kk] = b * STAGE + wm * TM * 128 + lanepart;
-                rb[b][kk] = b * STAGE + A_BYTES + wn * TN * 128 + lanepart;
-                asm volatile("" : "+v"(ra[b][kk]), "+v"(rb[b][kk]));  // opaque: four bases per operand, never re-derived
-            }
+            ra[kk] = wm * TM * 128 + lanepart;
+            rb[kk] = W_BASE + wn * TN * 128 + lanepart;
+            asm volatile("" : "+v"(ra[kk]), "+v"(rb[kk]));  // opaque: two bases per operand, never re-derived
         }
 #pragma unroll
         for (int i = 0; i < FM; ++i)
@@ -148,9 +149,10 @@ struct Gemm8 {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const char* src = (azero[H][i] ? Zb : Ab + arow[H][i]) + (size_t)kt * (BK * 2);
-            unsigned off = alane;
-            asm volatile("" : "+s"(src), "+v"(off));  // scalar base + 32-bit lane offset, zero-extended HERE: saddr form
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + off), lds_at(B * STAGE + alds[H][i]), 16, 0, 0);
+            // scalar base + 32-bit lane offset, zero-extended HERE: saddr form.  The lane offset is made opaque IN PLACE
+            // (no copy: the 320-row tile has no register to spare for one).
+            asm volatile("" : "+s"(src), "+v"(alane));
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + alane), lds_at(B * A_BYTES + alds[H][i]), 16, 0, 0);
         }
     }
     template <int B, int H>
@@ -158,9 +160,8 @@ struct Gemm8 {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const char* src = Wb + wrow[H][i] + (size_t)kt * (BK * 2);
-            unsigned off = wlane;
-            asm volatile("" : "+s"(src), "+v"(off));
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + off), lds_at(B * STAGE + wlds[H][i]), 16, 0, 0);
+            asm volatile("" : "+s"(src), "+v"(wlane));
+            __builtin_amdgcn_global_load_lds((gptr_t)(src + wlane), lds_at(B * B_BYTES + wlds[H][i]), 16, 0, 0);
         }
     }
     template <int B, int H>
@@ -168,14 +169,14 @@ struct Gemm8 {
 #pragma unroll
         for (int mi = 0; mi < (H ? FA1 : FA0); ++mi)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) af[mi][kk] = *lds_frag(ra[B][kk] + ((H ? FA0 * 16 : 0) + mi * 16) * 128);
+            for (int kk = 0; kk < 2; ++kk) af[mi][kk] = *lds_frag(ra[kk] + B * A_BYTES + ((H ? FA0 * 16 : 0) + mi * 16) * 128);
     }
     template <int B, int H>
     MM_DEVICE void read_b(bf16x8 (&bf)[FB][2]) {
 #pragma unroll
         for (int nj = 0; nj < FB; ++nj)
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) bf[nj][kk] = *lds_frag(rb[B][kk] + (H * FB * 16 + nj * 16) * 128);
+            for (int kk = 0; kk < 2; ++kk) bf[nj][kk] = *lds_frag(rb[kk] + B * B_BYTES + (H * FB * 16 + nj * 16) * 128);
     }
     template <int H, int NH, bool SWAP>
     MM_DEVICE void mma(bf16x8 (&bf)[FB][2]) {
@@ -198,26 +199,23 @@ struct Gemm8 {
     MM_DEVICE void tile(int kt) {
         constexpr int FOUR = NA0 + NA1 + 2 * NB;  // this wave's LDS-DMA instructions of four half-tiles
         // ---- P1: quadrant (A0, B0) ----
-        if (!(OPT & 2) && TAIL < 2) stage_w<B ^ 1, 1>(kt + 1);
+        if (TAIL < 2) stage_w<B ^ 1, 1>(kt + 1);
         read_a<B, 0>();
         read_b<B, 0>(bf0);
-        if ((OPT & 2) && TAIL < 2) stage_w<B ^ 1, 1>(kt + 1);
         if (TAIL < 2) wait_vm<FOUR>(); else wait_vm<NA1>();  // B1(kt) has landed
         G8_BARRIER();
         mma<0, 0, SWAP>(bf0);
         G8_BARRIER();
         // ---- P2: (A0, B1) ----
-        if (!(OPT & 2) && TAIL < 2) stage_a<B ^ 1, 1, NA1>(kt + 1);
+        if (TAIL < 2) stage_a<B ^ 1, 1, NA1>(kt + 1);
         read_b<B, 1>(bf1);
-        if ((OPT & 2) && TAIL < 2) stage_a<B ^ 1, 1, NA1>(kt + 1);
         if (TAIL < 2) wait_vm<FOUR>(); else wait_vm<0>();    // A1(kt) has landed
         G8_BARRIER();
         mma<0, 1, SWAP>(bf1);
         G8_BARRIER();
         // ---- P3: (A1, B1) ----
-        if (!(OPT & 2) && TAIL == 0) stage_a<B, 0, NA0>(kt + 2);
+        if (TAIL == 0) stage_a<B, 0, NA0>(kt + 2);
         read_a<B, 1>();
-        if ((OPT & 2) && TAIL == 0) stage_a<B, 0, NA0>(kt + 2);
         G8_BARRIER();
         mma<1, 1, SWAP>(bf1);
         G8_BARRIER();
@@ -230,23 +228,78 @@ struct Gemm8 {
         G8_BARRIER();
     }
 
+
+    // The same K-tile with BALANCED reads (OPT bit 1): one half-tile staged, read and retired per phase.
+    // LDS-DMA queue, oldest first, at the top of P1(kt): B1(kt) A1(kt) B0(kt+1) A0(kt+1)  (A0 of kt has landed; B0 of kt is
+    // already in registers: it was read during P4 of the previous K-tile, into the W register set that P3 had just
+    // released — the two sets swap roles from one K-tile to the next, which is the buffer parity B).  Every phase stages
+    // one half-tile, reads one half-tile and retires one half-tile; four half-tiles stay in flight behind every wait.
+    template <int B, int NA0, int NA1, int TAIL, bool SWAP>
+    MM_DEVICE void tile_bal(int kt) {
+        constexpr int FOUR = NA0 + NA1 + 2 * NB;  // this wave's LDS-DMA instructions of four half-tiles
+        bf16x8(&F)[FB][2] = B ? bf1 : bf0;        // holds W half 0 of this K-tile
+        bf16x8(&S)[FB][2] = B ? bf0 : bf1;        // W half 1 of this K-tile, then W half 0 of the next one
+        // ---- P1: quadrant (A0, B0) ----
+        if (TAIL < 2) stage_w<B ^ 1, 1>(kt + 1);
+        read_a<B, 0>();
+        if (TAIL < 2) wait_vm<FOUR>(); else wait_vm<NA1>();  // B1(kt) has landed
+        G8_BARRIER();
+        mma<0, 0, SWAP>(F);
+        G8_BARRIER();
+        // ---- P2: (A0, B1) ----
+        if (TAIL < 2) stage_a<B ^ 1, 1, NA1>(kt + 1);
+        read_b<B, 1>(S);
+        if (TAIL < 2) wait_vm<FOUR>(); else wait_vm<0>();    // A1(kt) has landed
+        G8_BARRIER();
+        mma<0, 1, SWAP>(S);
+        G8_BARRIER();
+        // ---- P3: (A1, B1) ----
+        if (TAIL == 0) stage_w<B, 0>(kt + 2);
+        read_a<B, 1>();
+        if (TAIL == 0) wait_vm<FOUR>();                      // B0(kt+1) has landed
+        else if (TAIL == 1) wait_vm<NA0 + NB + NA1>();
+        G8_BARRIER();
+        mma<1, 1, SWAP>(S);
+        G8_BARRIER();
+        // ---- P4: (A1, B0) ----
+        if (TAIL == 0) stage_a<B, 0, NA0>(kt + 2);
+        if (TAIL < 2) read_b<B ^ 1, 0>(S);
+        if (TAIL == 0) wait_vm<FOUR>();                      // A0(kt+1) has landed
+        else if (TAIL == 1) wait_vm<NB + NA1>();
+        G8_BARRIER();
+        mma<1, 0, SWAP>(F);
+        G8_BARRIER();
+    }
+
     template <int NA0, int NA1, bool SWAP>
     MM_DEVICE void run(int nk, int grp) {
+        constexpr bool BAL = (OPT & 2) != 0;
         // the vector-memory queue is empty here at run time; saying so keeps the static check of the counted waits
         // (tools/isa_check.py) independent of how the compiler lays the two code paths out
         wait_vm<0>();
         stage_a<0, 0, NA0>(0); stage_w<0, 0>(0); stage_w<0, 1>(0); stage_a<0, 1, NA1>(0);
-        stage_a<1, 0, NA0>(1); stage_w<1, 0>(1);
+        if (BAL) { stage_w<1, 0>(1); stage_a<1, 0, NA0>(1); }
+        else { stage_a<1, 0, NA0>(1); stage_w<1, 0>(1); }
         wait_vm<NA0 + NA1 + 2 * NB>();
         G8_BARRIER();
+        if (BAL) read_b<0, 0>(bf0);
         if (grp == 1) G8_BARRIER();  // waves 4-7 run one barrier behind waves 0-3
         if ((OPT & 1) && grp == 1) __builtin_amdgcn_s_setprio(1);
-        for (int kt = 0; kt + 2 < nk; kt += 2) {
-            tile<0, NA0, NA1, 0, SWAP>(kt);
-            tile<1, NA0, NA1, 0, SWAP>(kt + 1);
+        if constexpr (BAL) {
+            for (int kt = 0; kt + 2 < nk; kt += 2) {
+                tile_bal<0, NA0, NA1, 0, SWAP>(kt);
+                tile_bal<1, NA0, NA1, 0, SWAP>(kt + 1);
+            }
+            tile_bal<0, NA0, NA1, 1, SWAP>(nk - 2);
+            tile_bal<1, NA0, NA1, 2, SWAP>(nk - 1);
+        } else {
+            for (int kt = 0; kt + 2 < nk; kt += 2) {
+                tile<0, NA0, NA1, 0, SWAP>(kt);
+                tile<1, NA0, NA1, 0, SWAP>(kt + 1);
+            }
+            tile<0, NA0, NA1, 1, SWAP>(nk - 2);
+            tile<1, NA0, NA1, 2, SWAP>(nk - 1);
         }
-        tile<0, NA0, NA1, 1, SWAP>(nk - 2);
-        tile<1, NA0, NA1, 2, SWAP>(nk - 1);
         if (grp == 0) G8_BARRIER();
     }
 };
@@ -301,16 +354,18 @@ template <int EPI>
 int launch_epi8(int cfg, const GemmArgs& g, hipStream_t s) {
     constexpr int SW = EPI == EPI_QKV ? 2 : 1;
     switch (cfg) {
-        case GEMM8_320x256: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW>>(g, s);
-        case GEMM8_256x256: return launch_cfg8<EPI, Gemm8<256, 256, 2, 4, SW>>(g, s);
-        case GEMM8_160x256: return launch_cfg8<EPI, Gemm8<160, 256, 2, 4, SW>>(g, s);
-        case GEMM8_320x128: return launch_cfg8<EPI, Gemm8<320, 128, 4, 2, SW>>(g, s);
+        // the balanced read schedule (OPT 2) wherever it fits the registers: +1-3 % (profiles/r03_gemm8_sweep5_balanced.txt);
+        // the 320 x 256 tile spills inside the loop with it in the RESID / QKV epilogue builds and gains nothing on gate/up
+        case GEMM8_320x256: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 0>>(g, s);
+        case GEMM8_256x256: return launch_cfg8<EPI, Gemm8<256, 256, 2, 4, SW, 2>>(g, s);
+        case GEMM8_160x256: return launch_cfg8<EPI, Gemm8<160, 256, 2, 4, SW, 2>>(g, s);
+        case GEMM8_320x128: return launch_cfg8<EPI, Gemm8<320, 128, 4, 2, SW, 2>>(g, s);
 #ifdef MMADA_TUNE
         case 4: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 1>>(g, s);
-        case 5: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 2>>(g, s);
-        case 6: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 3>>(g, s);
-        case 7: return launch_cfg8<EPI, Gemm8<256, 256, 2, 4, SW, 2>>(g, s);
-        case 8: return launch_cfg8<EPI, Gemm8<160, 256, 2, 4, SW, 2>>(g, s);
+        case 5: return launch_cfg8<EPI, Gemm8<320, 128, 4, 2, SW, 0>>(g, s);
+        case 6: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 2>>(g, s);
+        case 7: return launch_cfg8<EPI, Gemm8<256, 256, 2, 4, SW, 0>>(g, s);
+        case 8: return launch_cfg8<EPI, Gemm8<160, 256, 2, 4, SW, 0>>(g, s);
 #endif
     }
     return mm_fail("gemm8: unknown configuration %d", cfg);

@@ -178,12 +178,27 @@ MM_DEVICE void gemm_epilogue(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[TM 
 // (W fragment as the A operand, activation fragment as the B operand), which computes the transposed 16 x 16 block with the
 // same products in the same k order:
 //     acc[mi][ni][r] = D[m][n],  m = m0 + wm*TM + mi*16 + (lane&15),  n = n0 + wn*TN + ni*16 + (lane>>4)*4 + r
-// — a lane now owns FOUR CONSECUTIVE COLUMNS of one row, so every residual read, rotary-table read and output write of a
-// lane is one 8- or 16-byte access instead of four 2-byte ones (a 160 x 64 wave tile: 40 instead of 160 store
-// instructions per lane; the epilogue of a short-K launch such as attn_out was ~30 % of its time, round-3 profile).
+// — a lane now owns FOUR CONSECUTIVE COLUMNS of one row, and after one half-row exchange between lanes (swap_halves16)
+// EIGHT: every residual read and output write of a lane is one 16-byte access instead of eight 2-byte ones (a 160 x 64
+// wave tile: 20 instead of 160 store instructions per lane; the epilogue of a short-K launch such as attn_out was ~30 %
+// of its time, round-3 profile).
 // The V columns of the QKV projection are the exception: vT is K-major, so there the untransposed layout (four consecutive
 // KEYS of one feature per lane) is the coalesced one — gemm8 picks the operand order per wave (qkv_wave_is_v).
 MM_DEVICE bool qkv_wave_is_v(const GemmArgs& g, int wcol0) { return (wcol0 >> 7) >= g.Hq + g.Hkv; }
+
+// Two adjacent 16-column fragments of a lane's row, each held as 4 consecutive columns per lane (2 packed dwords), become ONE
+// run of 8 consecutive columns per lane: v_permlane16_swap exchanges lanes 16-31 / 48-63 of the first register with lanes
+// 0-15 / 32-47 of the second, so afterwards (lq = lane >> 4)
+//     lq 0: {a, b} = columns 0-7 of the FIRST fragment        lq 1: columns 0-7  of the SECOND fragment
+//     lq 2:          columns 8-15 of the first                lq 3: columns 8-15 of the second
+// — one 16-byte access per lane instead of two 8-byte ones (the store tail of a tile is issue-bound: guide T21).
+MM_DEVICE void swap_halves16(uint32_t& a, uint32_t& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+// column (inside the 32-column pair) of the 8-column run a lane holds after swap_halves16
+MM_DEVICE int run8_col(int lq) { return (lq & 1) * 16 + (lq >> 1) * 8; }
 
 template <int EPI, int TM, int TN, int WN>
 MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[TM / 16][TN / 16], int wave, int lane) {
@@ -198,7 +213,7 @@ MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[T
 #pragma unroll
         for (int mi = 0; mi < FM; ++mi) {
             const int m = mrow0 + mi * 16;
-            if (m >= g.M) continue;
+            const bool live = m < g.M;  // the swaps below are wave-wide: every lane takes part, dead rows only skip memory
             // wave-uniform: the 16 rows of a fragment share one residual owner
             const bool add = EPI == EPI_RESID && (g.resid_mod == 1 || ((m >> 4) % g.resid_mod) == g.resid_rank);
             size_t rrow = (size_t)m;  // residual row (compact -> full layout when a row window is active)
@@ -207,52 +222,56 @@ MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[T
                 rrow = (size_t)bb * g.rlp + g.rbeg + (m - bb * g.rwin);
             }
 #pragma unroll
-            for (int ni = 0; ni < FN; ++ni) {
-                const int n = wcol0 + ni * 16 + lq * 4;
-                if (n >= g.N) continue;  // N is a multiple of 8 here: a lane's four columns are all inside or all outside
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[mi][ni][r];
+            for (int ni = 0; ni < FN; ni += 2) {
+                // every nn.Linear output is rounded to bf16 first (exactly representable afterwards: the exchange is lossless)
+                uint32_t a0 = pack_bf2(acc[mi][ni][0], acc[mi][ni][1]), a1 = pack_bf2(acc[mi][ni][2], acc[mi][ni][3]);
+                uint32_t b0 = pack_bf2(acc[mi][ni + 1][0], acc[mi][ni + 1][1]), b1 = pack_bf2(acc[mi][ni + 1][2], acc[mi][ni + 1][3]);
+                swap_halves16(a0, b0);
+                swap_halves16(a1, b1);
+                const int n = wcol0 + ni * 16 + run8_col(lq);
+                if (!live || n >= g.N) continue;  // N is a multiple of 8 here: a lane's eight columns are all inside or all outside
+                u32x4 o{a0, a1, b0, b1};
                 if constexpr (EPI == EPI_RESID) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = bfround(v[r]);
                     if (add) {
-                        const u32x2 rv = *(const u32x2*)(g.resid + rrow * g.ldr + n);
-                        v[0] += __uint_as_float(rv[0] << 16);
-                        v[1] += __uint_as_float(rv[0] & 0xffff0000u);
-                        v[2] += __uint_as_float(rv[1] << 16);
-                        v[3] += __uint_as_float(rv[1] & 0xffff0000u);
+                        const u32x4 rv = *(const u32x4*)(g.resid + rrow * g.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o[e] = pack_bf2(__uint_as_float(rv[e] << 16) + __uint_as_float(o[e] << 16),
+                                            __uint_as_float(rv[e] & 0xffff0000u) + __uint_as_float(o[e] & 0xffff0000u));
                     }
                 }
-                u32x2 pk;
-                pk[0] = pack_bf2(v[0], v[1]);
-                pk[1] = pack_bf2(v[2], v[3]);
-                *(u32x2*)(g.C + (size_t)m * g.ldc + n) = pk;
+                *(u32x4*)(g.C + (size_t)m * g.ldc + n) = o;
             }
         }
     } else if constexpr (EPI == EPI_SWIGLU) {
-        // columns come in 32-wide groups: [16 x ff_proj | 16 x up_proj] (see pack_gate_up); x = silu(ff_proj)*up
-        if (wcol0 < g.N) {
-            const int hcol0 = wcol0 / 2 + lq * 4;
+        // columns come in 32-wide groups: [16 x ff_proj | 16 x up_proj] (see pack_gate_up); x = silu(ff_proj)*up.  A 32-column
+        // group yields 16 output columns, 4 per lane; two adjacent groups are joined into runs of 8 like two fragments above.
+        static_assert((FN / 2) % 2 == 0, "SwiGLU epilogue joins the outputs of two 32-column groups");
+        const int hbase = wcol0 / 2;
 #pragma unroll
-            for (int mi = 0; mi < FM; ++mi) {
-                const int m = mrow0 + mi * 16;
-                if (m >= g.M) continue;
+        for (int mi = 0; mi < FM; ++mi) {
+            const int m = mrow0 + mi * 16;
+            const bool live = m < g.M;
 #pragma unroll
-                for (int q2 = 0; q2 < FN / 2; ++q2) {
-                    if (wcol0 + q2 * 32 >= g.N) continue;
+            for (int q2 = 0; q2 < FN / 2; q2 += 2) {
+                uint32_t pk[2][2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
                     float o[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        o[r] = silu_bf16(bfround(acc[mi][2 * q2][r])) * bfround(acc[mi][2 * q2 + 1][r]);
-                    u32x2 pk;
-                    pk[0] = pack_bf2(o[0], o[1]);
-                    pk[1] = pack_bf2(o[2], o[3]);
-                    *(u32x2*)(g.C + (size_t)m * g.ldc + hcol0 + q2 * 16) = pk;
+                        o[r] = silu_bf16(bfround(acc[mi][2 * (q2 + u)][r])) * bfround(acc[mi][2 * (q2 + u) + 1][r]);
+                    pk[u][0] = pack_bf2(o[0], o[1]);
+                    pk[u][1] = pack_bf2(o[2], o[3]);
                 }
+                swap_halves16(pk[0][0], pk[1][0]);
+                swap_halves16(pk[0][1], pk[1][1]);
+                if (!live || wcol0 + q2 * 32 >= g.N) continue;  // N is a multiple of 64: both groups are inside or outside
+                *(u32x4*)(g.C + (size_t)m * g.ldc + hbase + q2 * 16 + run8_col(lq)) = u32x4{pk[0][0], pk[0][1], pk[1][0], pk[1][1]};
             }
         }
     } else {  // EPI_QKV, q and k heads (a wave's TN columns lie inside one 128-wide head; V waves never come here)
+        static_assert((FN / 2) % 2 == 0, "QKV epilogue joins the outputs of two rotary groups");
         const int head = wcol0 >> 7, c0 = wcol0 & 127;
         const bool isq = head < g.Hq;
         bf16_t* dst = isq ? g.q : g.k;
@@ -261,8 +280,8 @@ MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[T
 #pragma unroll
         for (int mi = 0; mi < FM; ++mi) {
             const int m = mrow0 + mi * 16;
-            if (m >= g.M) continue;
-            const int mg = m + g.m_base;  // row of the whole [B*Lp] stream
+            bool live = m < g.M;
+            const int mg = min(m, g.M - 1) + g.m_base;  // row of the whole [B*Lp] stream (dead lanes: any valid row)
             const int b = mg / g.Lp;
             int l = mg - b * g.Lp;        // rotary position
             int lr = l, lstride = g.Lkv;  // destination row / rows per head
@@ -272,26 +291,33 @@ MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[T
                     lr = l; lstride = g.Lq;
                     l = g.q_pos_shift >= 0 ? l + g.q_pos_shift : (pos < 0 ? 0 : pos);
                 } else {
-                    if (pos < 0) continue;  // pad row of the compact stream: never enters the cache
-                    l = lr = pos;
+                    if (pos < 0) live = false;  // pad row of the compact stream: never enters the cache
+                    l = lr = max(pos, 0);
                 }
             }
             bf16_t* row = dst + ((size_t)(b * nh + hh) * lstride + lr) * 128;
 #pragma unroll
-            for (int q2 = 0; q2 < FN / 2; ++q2) {
-                // permuted column layout: fragments (2*q2, 2*q2+1) hold rotary partners i and i+64
-                const int i = (c0 / 32 + q2) * 16 + lq * 4;
-                const f32x4 cv = *(const f32x4*)(g.rope_cos + l * 64 + i);
-                const f32x4 sv = *(const f32x4*)(g.rope_sin + l * 64 + i);
-                float o1[4], o2[4];
+            for (int q2 = 0; q2 < FN / 2; q2 += 2) {
+                // permuted column layout: fragments (2*q, 2*q+1) hold rotary partners i and i+64, i = (c0/32 + q)*16 + lq*4 + r
+                uint32_t p1[2][2], p2[2][2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    rope_pair(bfround(acc[mi][2 * q2][r]), bfround(acc[mi][2 * q2 + 1][r]), cv[r], sv[r], o1[r], o2[r]);
-                u32x2 p1, p2;
-                p1[0] = pack_bf2(o1[0], o1[1]); p1[1] = pack_bf2(o1[2], o1[3]);
-                p2[0] = pack_bf2(o2[0], o2[1]); p2[1] = pack_bf2(o2[2], o2[3]);
-                *(u32x2*)(row + i) = p1;
-                *(u32x2*)(row + i + 64) = p2;
+                for (int u = 0; u < 2; ++u) {
+                    const int i = (c0 / 32 + q2 + u) * 16 + lq * 4;
+                    const f32x4 cv = *(const f32x4*)(g.rope_cos + l * 64 + i);
+                    const f32x4 sv = *(const f32x4*)(g.rope_sin + l * 64 + i);
+                    float o1[4], o2[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        rope_pair(bfround(acc[mi][2 * (q2 + u)][r]), bfround(acc[mi][2 * (q2 + u) + 1][r]), cv[r], sv[r], o1[r], o2[r]);
+                    p1[u][0] = pack_bf2(o1[0], o1[1]); p1[u][1] = pack_bf2(o1[2], o1[3]);
+                    p2[u][0] = pack_bf2(o2[0], o2[1]); p2[u][1] = pack_bf2(o2[2], o2[3]);
+                }
+                swap_halves16(p1[0][0], p1[1][0]); swap_halves16(p1[0][1], p1[1][1]);
+                swap_halves16(p2[0][0], p2[1][0]); swap_halves16(p2[0][1], p2[1][1]);
+                if (!live) continue;
+                const int i8 = (c0 / 32 + q2) * 16 + run8_col(lq);
+                *(u32x4*)(row + i8) = u32x4{p1[0][0], p1[0][1], p1[1][0], p1[1][1]};
+                *(u32x4*)(row + i8 + 64) = u32x4{p2[0][0], p2[0][1], p2[1][0], p2[1][1]};
             }
         }
     }

@@ -191,9 +191,12 @@ def test_pixel_token_helpers_match_the_reference_functions():
         iu.decode_vq_to_image(codes[:, :-1], None, None, 36, 70, vq)
 
 
-def _gemm8_program(nk, na0, na1, nb):
-    """Program order of ONE wave of csrc/gemm8.hip (Gemm8::run / Gemm8::tile): ('stage', half, tile), ('read', half, tile),
-    ('wait', n) and ('phase',) events.  Kept in step with the kernel by hand: it is the specification the kernel follows."""
+def _gemm8_program(nk, na0, na1, nb, balanced=False):
+    """Program order of ONE wave of csrc/gemm8.hip (Gemm8::run with Gemm8::tile, or Gemm8::tile_bal when `balanced`):
+    ('stage', half, tile), ('read', half, tile), ('wait', n) and ('phase',) events.  Kept in step with the kernel by hand:
+    it is the specification the kernel follows."""
+    if balanced:
+        return _gemm8_program_balanced(nk, na0, na1, nb)
     four = na0 + na1 + 2 * nb
     ev = [("wait", 0)]
     for n, t in (("A0", 0), ("B0", 0), ("B1", 0), ("A1", 0), ("A0", 1), ("B0", 1)):
@@ -218,8 +221,38 @@ def _gemm8_program(nk, na0, na1, nb):
     return ev
 
 
+def _gemm8_program_balanced(nk, na0, na1, nb):
+    """tile_bal: one half-tile staged, read and retired per phase; W half 0 of K-tile T+1 is read in P4 of K-tile T."""
+    four = na0 + na1 + 2 * nb
+    ev = [("wait", 0)]
+    for n, t in (("A0", 0), ("B0", 0), ("B1", 0), ("A1", 0), ("B0", 1), ("A0", 1)):
+        ev.append(("stage", n, t))
+    ev += [("wait", four), ("phase",), ("read", "B0", 0)]
+    for T in range(nk):
+        tail = 0 if T + 2 < nk else (1 if T == nk - 2 else 2)
+        if tail < 2:
+            ev.append(("stage", "B1", T + 1))
+        ev += [("read", "A0", T), ("wait", four if tail < 2 else na1), ("phase",)]
+        if tail < 2:
+            ev.append(("stage", "A1", T + 1))
+        ev += [("read", "B1", T), ("wait", four if tail < 2 else 0), ("phase",)]
+        if tail == 0:
+            ev.append(("stage", "B0", T + 2))
+        ev.append(("read", "A1", T))
+        if tail < 2:
+            ev.append(("wait", four if tail == 0 else na0 + nb + na1))
+        ev.append(("phase",))
+        if tail == 0:
+            ev.append(("stage", "A0", T + 2))
+        if tail < 2:
+            ev += [("read", "B0", T + 1), ("wait", four if tail == 0 else nb + na1)]
+        ev.append(("phase",))
+    return ev
+
+
+@pytest.mark.parametrize("balanced", [False, True])
 @pytest.mark.parametrize("na0,na1,nb", [(2, 2, 2), (3, 3, 2), (2, 1, 2), (1, 1, 2), (3, 2, 1)])
-def test_gemm8_schedule(na0, na1, nb):
+def test_gemm8_schedule(na0, na1, nb, balanced):
     """The LDS-DMA queue of the 8-phase GEMM, simulated in program order for every piece split the kernel instantiates:
     a half-tile is read only after a counted wait of an EARLIER phase retired all its pieces (RAW: the reader may be a
     wave of the other, one-barrier-late group), a slot is re-staged at least two phases after its last read (WAR), the
@@ -227,7 +260,7 @@ def test_gemm8_schedule(na0, na1, nb):
     cnt = {"A0": na0, "A1": na1, "B0": nb, "B1": nb}
     for nk in (2, 4, 6, 8, 64, 192):
         fifo, landed, slot, last_read, ph = [], {}, {}, {}, 0
-        for e in _gemm8_program(nk, na0, na1, nb):
+        for e in _gemm8_program(nk, na0, na1, nb, balanced):
             if e[0] == "phase":
                 ph += 1
             elif e[0] == "stage":
