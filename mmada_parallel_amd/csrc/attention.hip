@@ -239,12 +239,21 @@ MM_DEVICE lptr_t lds_at(int byte_off) { return (lptr_t)(uint32_t)byte_off; }
 // every step exposed an LDS round trip in front of 64 cycles of MFMA work.  Here the fragments run THREE k-steps (S) / four
 // MFMAs (PV) ahead of their use in registers, the order is pinned with sched_group_barrier, LDS addresses are per-lane
 // offsets + immediates (the two ring stages are compile-time constants: loop unrolled by two), the four O accumulators
-// are interleaved, and the eight LDS-DMA pieces of the next tile are issued one per MFMA pair inside the S block instead
-// of in one burst in front of it.
+// are interleaved, the eight LDS-DMA pieces of the next tile are issued one per MFMA pair inside the S block instead
+// of in one burst in front of it, the first vT fragments are requested before the soft-max and the half-row maximum is
+// exchanged with v_permlane32_swap instead of ds_bpermute (no LDS round trip between the maximum and the exponentials).
+// VAR (tuning builds only, tools/attn_sweep.py; the product instantiates VAR 0): 1-3 are DIAGNOSTIC (wrong results, timing
+// only) — 1: no soft-max arithmetic, 2: no MFMAs, 3: no tile barrier; 4: static s_setprio 1 for the workgroup whose LDS
+// allocation does not start at 0 (the second workgroup of the CU).
+template <int VAR>
 __global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ql = lane & 31, hi = lane >> 5;
+    if constexpr (VAR == 4) {
+        // HW_REG_LDS_ALLOC (id 6): LDS_BASE in bits 7:0
+        if (__builtin_amdgcn_s_getreg((6) | (0 << 6) | ((8 - 1) << 11)) != 0) __builtin_amdgcn_s_setprio(1);
+    }
     int qb, h, b;
     if (a.xcd_pairs > 0) {
         const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
@@ -313,7 +322,8 @@ __global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
         using Next = std::integral_constant<int, R ^ 1>;
         asm volatile("" : "+v"(kro[0]), "+v"(kro[1]), "+v"(kro[2]), "+v"(kro[3]), "+v"(kro[4]), "+v"(kro[5]), "+v"(kro[6]), "+v"(kro[7]));
         asm volatile("" : "+v"(vro[0]), "+v"(vro[1]), "+v"(vro[2]), "+v"(vro[3]));
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if constexpr (VAR == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         A8_SB();
         const bool more = kt + 1 < nkt;
         // ---- S^T = K · Q^T ----
@@ -329,8 +339,12 @@ __global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s % 3][0], qf[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s % 3][1], qf[s], s1, 0, 0, 0);
+            if constexpr (VAR == 2) {
+                asm volatile("" : "+v"(s0), "+v"(s1) : "v"(ka[s % 3][0]), "v"(ka[s % 3][1]));
+            } else {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s % 3][0], qf[s], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[s % 3][1], qf[s], s1, 0, 0, 0);
+            }
             if (s + 3 < 8) {
                 ka[s % 3][0] = lds_frag(kro[s + 3] + BASE);
                 ka[s % 3][1] = lds_frag(kro[s + 3] + BASE + 8192);
@@ -339,10 +353,15 @@ __global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
         __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+            if (VAR != 2) __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
             if (s + 3 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
             __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one LDS-DMA piece of the next tile (none in the last tile)
         }
+        A8_SB();
+        // the first vT fragments are requested BEFORE the soft-max: their LDS round trip runs under it
+        bf16x8 va[4];
+#pragma unroll
+        for (int db = 0; db < 4; ++db) va[db] = lds_frag(vro[0] + BASE + db * 4096);
         A8_SB();
         if (kt * KB + KB > a.L) {
             const int kbase = kt * KB + 4 * hi;
@@ -353,6 +372,7 @@ __global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
                 if (key + 32 >= a.L) s1[r] = -INFINITY;
             }
         }
+        if constexpr (VAR != 1) {
         float mxa = fmaxf(s0[0], s1[0]), mxb = fmaxf(s0[1], s1[1]);
 #pragma unroll
         for (int r = 2; r < 16; r += 2) {
@@ -360,7 +380,10 @@ __global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
             mxb = max3f(mxb, s0[r + 1], s1[r + 1]);
         }
         float mx = fmax_nc(mxa, mxb);
-        mx = fmax_nc(mx, __shfl_xor(mx, 32, 64)) * a.scale_log2e;
+        {  // the other half-row's maximum by v_permlane32_swap (VALU) instead of ds_bpermute (an LDS round trip on the critical path)
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+            mx = fmax_nc(__uint_as_float(sw[0]), __uint_as_float(sw[1])) * a.scale_log2e;
+        }
         if (!__all(mx - m_run <= DEFER_LOG2)) {
             const float m_new = fmax_nc(m_run, mx);
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -379,6 +402,7 @@ __global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
             psum += s0[r] + s1[r];
         }
         l_run += psum;
+        }
         bf16x8 pb[2][2];
 #pragma unroll
         for (int s2 = 0; s2 < 2; ++s2)
@@ -389,22 +413,19 @@ __global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
             }
         A8_SB();
         // ---- O^T += V^T · P^T ----
-        bf16x8 va[4];
-#pragma unroll
-        for (int db = 0; db < 4; ++db) va[db] = lds_frag(vro[0] + BASE + db * 4096);
 #pragma unroll
         for (int n = 0; n < 16; ++n) {
             const int j = n >> 2, db = n & 3;
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[db], pb[j >> 1][j & 1], o[db], 0, 0, 0);
+            if constexpr (VAR == 2) asm volatile("" : "+v"(o[db]) : "v"(va[db]), "v"(pb[j >> 1][j & 1]));
+            else o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[db], pb[j >> 1][j & 1], o[db], 0, 0, 0);
             if (n + 4 < 16) va[db] = lds_frag(vro[j + 1] + BASE + db * 4096);
         }
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 1);
 #pragma unroll
         for (int n = 0; n < 12; ++n) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+            if (VAR != 2) __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
+        if (VAR != 2) __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
         A8_SB();
     };
     int kt = 0;
@@ -459,11 +480,26 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
         g_attn_form = e ? atoi(e) : 1;
     }
     const int nq = (Lq_rows - q_begin + QB - 1) / QB;
-    auto fn = g_attn_form == 1 ? attn4p_fwd_kernel : attn_fwd_kernel;
-    if (g_attn_form == 1) {
+    auto fn = g_attn_form == 1 ? attn4p_fwd_kernel<0> : attn_fwd_kernel;
+#ifdef MMADA_TUNE
+    switch (g_attn_form) {  // 11-13: diagnostic (wrong results), 14: static priority for the CU's second workgroup
+        case 11: fn = attn4p_fwd_kernel<1>; break;
+        case 12: fn = attn4p_fwd_kernel<2>; break;
+        case 13: fn = attn4p_fwd_kernel<3>; break;
+        case 14: fn = attn4p_fwd_kernel<4>; break;
+    }
+#endif
+    if (g_attn_form != 0) {
         static bool attr4[16] = {};
-        if (mm_first_use_on_device(attr4))
-            MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
+        if (mm_first_use_on_device(attr4)) {
+            MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
+#ifdef MMADA_TUNE
+            MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
+            MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
+            MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
+            MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
+#endif
+        }
     }
     if (xcd_aware && pairs % 8 == 0) {
         a.xcd_pairs = pairs / 8; a.nq = nq;

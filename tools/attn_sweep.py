@@ -30,7 +30,13 @@ def main():
     ap.add_argument("--iters", type=int, default=25)
     ap.add_argument("--rounds", type=int, default=14)
     ap.add_argument("--warm", type=int, default=3000)
+    ap.add_argument("--forms", default="0,1", help="attention forms to interleave; forms > 1 exist in the -DMMADA_TUNE build only "
+                    "(11: no soft-max, 12: no MFMA, 13: no tile barrier — DIAGNOSTIC, wrong results; 14: static priority)")
     args = ap.parse_args()
+    forms = [int(f) for f in args.forms.split(",")]
+    if max(forms) > 1:
+        from tools.tune.build_tune import build_product_tune
+        os.environ["MMADA_MI355X_LIB"] = build_product_tune()
     lib = abi.lib()
     cfg = synth.CFG_8B
     c = abi.MmadaCfg(d_model=cfg["d_model"], n_layers=1, n_heads=32, n_kv_heads=32, head_dim=128, mlp_hidden=12288,
@@ -55,9 +61,9 @@ def main():
 
     run(args.warm)  # ~1 s of load: the clock governor settles
     torch.cuda.synchronize()
-    ms = {0: [], 1: []}
+    ms = {f: [] for f in forms}
     for _ in range(args.rounds):   # the two kernel forms interleaved in rounds (same clock, same heat)
-        for form in (0, 1):        # 0: round-2 issue order; 1: software-pipelined matrix blocks (the default)
+        for form in forms:         # 0: round-2 issue order; 1: software-pipelined matrix blocks (the default)
             abi.check(lib.mmada_set_option(b"attention_form", form), "set_option")
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -66,9 +72,11 @@ def main():
             torch.cuda.synchronize()
             ms[form].append(e0.elapsed_time(e1) / args.iters)
     lib.mmada_set_option(b"attention_form", -1)
-    for form in (0, 1):
+    names = {0: "round-2 issue order", 1: "pipelined matrix blocks", 11: "DIAG no soft-max", 12: "DIAG no MFMA", 13: "DIAG no barrier",
+             14: "static priority, second workgroup"}
+    for form in forms:
         t = sorted(ms[form])[len(ms[form]) // 2]
-        print(f"B={B} L={L} form {form} ({'pipelined matrix blocks' if form else 'round-2 issue order'}): median {t * 1e3:.1f} us per "
+        print(f"B={B} L={L} form {form} ({names.get(form, '?')}): median {t * 1e3:.1f} us per "
               f"mmada_sdpa call (incl. 3 layout kernels) = {flops / t / 1e9:.0f} TF lower bound over {args.rounds} rounds of {args.iters}")
     ref = torch.nn.functional.scaled_dot_product_attention(q[:, :2].float(), k[:, :2].float(), v[:, :2].float())
     got = out.view(B, L, H, 128)[:, :, :2].permute(0, 2, 1, 3).float()

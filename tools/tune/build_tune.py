@@ -22,5 +22,24 @@ def build(force=False):
     return LIB
 
 
+PRODUCT_TUNE_LIB = os.path.join(os.path.dirname(HERE), "libmmada_mi355x_tune.so")
+
+
+def build_product_tune(force=False):
+    """The whole product library compiled with -DMMADA_TUNE (extra GEMM configurations, diagnostic attention variants):
+    load it instead of the product with MMADA_MI355X_LIB=<path> (tools/attn_sweep.py --forms does)."""
+    from mmada_parallel_amd import build as pb
+
+    srcs = [os.path.join(CSRC, s) for s in pb.SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in pb.HEADERS]
+    if not force and os.path.exists(PRODUCT_TUNE_LIB) and all(os.path.getmtime(d) < os.path.getmtime(PRODUCT_TUNE_LIB) for d in deps):
+        return PRODUCT_TUNE_LIB
+    cmd = [pb._hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-DMMADA_TUNE", "-I", CSRC,
+           "-I", os.path.join(ROOT, "include")] + srcs + ["-o", PRODUCT_TUNE_LIB]
+    subprocess.run(cmd, check=True)
+    return PRODUCT_TUNE_LIB
+
+
 if __name__ == "__main__":
     print(build(force=True))
+    print(build_product_tune(force=True))
