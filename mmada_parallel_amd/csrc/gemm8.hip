@@ -66,7 +66,8 @@ MM_DEVICE void wait_vm() {
 // layout of gemm_epilogue_t (a lane owns four consecutive columns of a row: 8-byte epilogue accesses);  2: chosen per wave
 // (`swap`): the QKV projection, whose V waves want the untransposed layout.  Same products, same k order: same bits.
 // OPT: bit 0 = static s_setprio 1 for the late wave group (tuning builds only, tools/gemm_sweep.py);  bit 1 = balanced
-// read schedule (tile_bal).
+// read schedule (tile_bal);  bits 2-4 are DIAGNOSTIC (tuning builds, wrong results, timing only): 4 = no MFMAs, 8 = no
+// LDS-DMA, 16 = no ds_reads.
 template <int BM_, int BN_, int WM_, int WN_, int SW_, int OPT_ = 0>
 struct Gemm8 {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, SW = SW_, OPT = OPT_;
@@ -142,10 +143,23 @@ struct Gemm8 {
         for (int i = 0; i < FM; ++i)
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (OPT & 16) {  // diagnostic build without ds_reads: operands that are not zeros (MFMAs on zeros draw less power)
+            bf16x8 junk;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) junk[e] = (__bf16)(0.37f + 0.01f * (float)((lane * 7 + e * 13) & 63));
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int i = 0; i < FA0; ++i) af[i][kk] = junk;
+#pragma unroll
+                for (int j = 0; j < FB; ++j) { bf0[j][kk] = junk; bf1[j][kk] = junk; }
+            }
+        }
     }
 
     template <int B, int H, int NA>
     MM_DEVICE void stage_a(int kt) {
+        if (OPT & 8) return;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const char* src = (azero[H][i] ? Zb : Ab + arow[H][i]) + (size_t)kt * (BK * 2);
@@ -157,6 +171,7 @@ struct Gemm8 {
     }
     template <int B, int H>
     MM_DEVICE void stage_w(int kt) {
+        if (OPT & 8) return;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const char* src = Wb + wrow[H][i] + (size_t)kt * (BK * 2);
@@ -166,6 +181,7 @@ struct Gemm8 {
     }
     template <int B, int H>
     MM_DEVICE void read_a() {
+        if (OPT & 16) return;
 #pragma unroll
         for (int mi = 0; mi < (H ? FA1 : FA0); ++mi)
 #pragma unroll
@@ -173,6 +189,7 @@ struct Gemm8 {
     }
     template <int B, int H>
     MM_DEVICE void read_b(bf16x8 (&bf)[FB][2]) {
+        if (OPT & 16) return;
 #pragma unroll
         for (int nj = 0; nj < FB; ++nj)
 #pragma unroll
@@ -187,6 +204,7 @@ struct Gemm8 {
 #pragma unroll
                 for (int nj = 0; nj < FB; ++nj) {
                     f32x4& c = acc[(H ? FA0 : 0) + mi][NH * FB + nj];
+                    if (OPT & 4) { asm volatile("" : "+v"(c) : "v"(af[mi][kk]), "v"(bf[nj][kk])); continue; }
                     c = SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[nj][kk], af[mi][kk], c, 0, 0, 0)
                              : __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi][kk], bf[nj][kk], c, 0, 0, 0);
                 }
@@ -366,6 +384,11 @@ int launch_epi8(int cfg, const GemmArgs& g, hipStream_t s) {
         case 6: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 2>>(g, s);
         case 7: return launch_cfg8<EPI, Gemm8<256, 256, 2, 4, SW, 0>>(g, s);
         case 8: return launch_cfg8<EPI, Gemm8<160, 256, 2, 4, SW, 0>>(g, s);
+        case 9: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 4>>(g, s);    // DIAG: no MFMA
+        case 10: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 8>>(g, s);   // DIAG: no LDS-DMA
+        case 11: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 16>>(g, s);  // DIAG: no ds_reads
+        case 12: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 24>>(g, s);  // DIAG: MFMAs + barriers only
+        case 13: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 20>>(g, s);  // DIAG: LDS-DMA + barriers only
 #endif
     }
     return mm_fail("gemm8: unknown configuration %d", cfg);
