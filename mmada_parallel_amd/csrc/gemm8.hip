@@ -66,8 +66,8 @@ MM_DEVICE void wait_vm() {
 // layout of gemm_epilogue_t (a lane owns four consecutive columns of a row: 8-byte epilogue accesses);  2: chosen per wave
 // (`swap`): the QKV projection, whose V waves want the untransposed layout.  Same products, same k order: same bits.
 // OPT: bit 0 = static s_setprio 1 for the late wave group (tuning builds only, tools/gemm_sweep.py);  bit 1 = balanced
-// read schedule (tile_bal);  bits 2-4 are DIAGNOSTIC (tuning builds, wrong results, timing only): 4 = no MFMAs, 8 = no
-// LDS-DMA, 16 = no ds_reads.
+// read schedule (tile_bal);  bits 2-4 and 6 are DIAGNOSTIC (tuning builds, wrong results, timing only): 4 = no MFMAs,
+// 8 = no LDS-DMA, 16 = no ds_reads, 64 = every tile streams the operand panels of tile (0, 0).
 template <int BM_, int BN_, int WM_, int WN_, int SW_, int OPT_ = 0>
 struct Gemm8 {
     static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, SW = SW_, OPT = OPT_;
@@ -104,8 +104,8 @@ struct Gemm8 {
     f32x4 acc[FM][FN];
 
     MM_DEVICE void init(const GemmArgs& g, int m0, int n0, int wave, int lane) {
-        Ab = (const char*)(g.A + (size_t)m0 * g.lda);
-        Wb = (const char*)(g.W + (size_t)n0 * g.ldw);
+        Ab = (const char*)(g.A + (size_t)((OPT & 64) ? 0 : m0) * g.lda);  // OPT 64 (diagnostic): every tile streams the panels of
+        Wb = (const char*)(g.W + (size_t)((OPT & 64) ? 0 : n0) * g.ldw);  // tile (0, 0) — an operand stream without L2 misses
         Zb = (const char*)g.zero_row;
         const int wm = wave / WN, wn = wave % WN;
         const int prow = lane >> 3, psw = ((wave & 1) * 4 + (prow >> 1)) & 7;
@@ -389,6 +389,8 @@ int launch_epi8(int cfg, const GemmArgs& g, hipStream_t s) {
         case 11: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 16>>(g, s);  // DIAG: no ds_reads
         case 12: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 24>>(g, s);  // DIAG: MFMAs + barriers only
         case 13: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 20>>(g, s);  // DIAG: LDS-DMA + barriers only
+        case 14: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 84>>(g, s);  // DIAG: LDS-DMA + barriers only, no L2 misses
+        case 15: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 64>>(g, s);  // DIAG: whole kernel, no L2 misses
 #endif
     }
     return mm_fail("gemm8: unknown configuration %d", cfg);
