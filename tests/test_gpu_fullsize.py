@@ -67,6 +67,31 @@ def test_batch_invariance_and_determinism_full_length(block8b):
     assert torch.equal(c[1], a[0]), "a sequence's result must not depend on what shares the batch"
 
 
+def test_block_is_bit_identical_under_every_gemm_configuration(block8b):
+    """One 8B block (QKV + rotary, attn_out + residual, gate/up + SiLU*mul, down + residual) with every GEMM of it pinned to
+    each tile configuration in turn: the fused epilogues of the 8-phase kernel (transposed accumulator, 16-byte accesses after
+    the half-row lane exchange, both read schedules) and of the 16-wave kernel (one element per access) must produce the
+    same bits — the planner's choice, which depends on the batch, may never show in a result."""
+    _, _, model = block8b
+    job = synth.synthetic_job(512, 512, text_gen_length=256, prompt_len=64, uncond_prompt_len=24, seed=1)
+    ids1 = job["input_ids"].to(DEV)
+    ids2 = torch.cat([ids1, ids1.flip(1)], 0)
+    lib = abi.lib()
+    try:
+        for ids in (ids1, ids2, ids1[:, :333]):
+            ref = None
+            for code in (-1, 0, 1, 2, 3, 1160, 1256, 1320):
+                abi.check(lib.mmada_set_option(b"gemm_config", code), "set_option")
+                model.forward_body(ids)
+                got = model.hidden_state().clone()
+                assert torch.isfinite(got.float()).all()
+                if ref is None:
+                    ref = got
+                assert torch.equal(got, ref), f"gemm_config {code}, ids {tuple(ids.shape)}: {int((got != ref).sum())} elements differ"
+    finally:
+        lib.mmada_set_option(b"gemm_config", -1)
+
+
 def test_sampler_counting_invariants_full_size(block8b):
     """generate_ti2ti at the full sampler sizes on stub logits: integer invariants that hold for any logits."""
     from mmada_parallel_amd import LLaDAForMultiModalGeneration
