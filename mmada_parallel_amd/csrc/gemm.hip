@@ -194,7 +194,7 @@ Plan plan(const GemmArgs& g) {
     }
     const bool can8 = gemm8_supports(g);
 #ifdef MMADA_TUNE
-    if (g_force >= 0 && g_force < GEMM8_NCFG + 16 && can8) return {true, g_force};
+    if (g_force >= 0 && g_force < GEMM8_NCFG + 20 && can8) return {true, g_force};
 #endif
     if (g_force >= 0 && g_force < GEMM8_NCFG && can8) return {true, g_force};
     if (g_force >= 1000) {

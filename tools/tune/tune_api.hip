@@ -28,7 +28,7 @@ int mmada_gemm_variant(int variant, const void* A, const void* W, void* C, int M
     g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N;
     // 100: production planner; 300 + c: production with the 8-phase configuration c forced; 1000 + BM: production with the
     // 16-wave kernel's row tile forced
-    if (variant == 100 || (variant >= 300 && variant < 300 + GEMM8_NCFG + 16) || variant >= 1000) {
+    if (variant == 100 || (variant >= 300 && variant < 300 + GEMM8_NCFG + 20) || variant >= 1000) {
         gemm_force_config(variant == 100 ? -1 : variant >= 1000 ? variant : variant - 300);
         const int rc = launch_gemm(EPI_STORE, g, (hipStream_t)stream);
         gemm_force_config(-1);
