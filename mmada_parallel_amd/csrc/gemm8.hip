@@ -400,8 +400,10 @@ int launch_epi8(int cfg, const GemmArgs& g, hipStream_t s) {
 
 bool gemm8_supports(const GemmArgs& g) {
     // two K-tiles per loop iteration and a two-tile tail; whole 8-row LDS-DMA pieces; 32-bit source offsets inside a tile
+    // ... and 16-byte epilogue accesses: leading dimensions of C and of the residual in whole 8-element groups
     return g.K % 128 == 0 && g.K >= 256 && g.M % 8 == 0 && g.N % 8 == 0 && g.M >= 8 && g.N >= 8 &&
-           (long long)g.lda * 2 * 328 < (1ll << 31) && (long long)g.ldw * 2 * 264 < (1ll << 31);
+           (long long)g.lda * 2 * 328 < (1ll << 31) && (long long)g.ldw * 2 * 264 < (1ll << 31) &&
+           g.ldc % 8 == 0 && (g.resid == nullptr || g.ldr % 8 == 0) && ((uintptr_t)g.C & 15) == 0 && ((uintptr_t)g.resid & 15) == 0;
 }
 
 int launch_gemm8(int epi, int cfg, const GemmArgs& g, hipStream_t s) {
