@@ -63,7 +63,7 @@ MM_DEVICE void wait_vm() {
 }
 
 // SW: operand roles of the MFMAs.  0: (activation, weight) — the C layout of gemm_epilogue;  1: swapped, the transposed C
-// layout of gemm_epilogue_t (a lane owns four consecutive columns of a row: 8-byte epilogue accesses);  2: chosen per wave
+// layout of gemm_epilogue_t (a lane owns four consecutive columns of a row, eight after a half-row exchange: 16-byte epilogue accesses);  2: chosen per wave
 // (`swap`): the QKV projection, whose V waves want the untransposed layout.  Same products, same k order: same bits.
 // OPT: bit 0 = static s_setprio 1 for the late wave group (tuning builds only, tools/gemm_sweep.py);  bit 1 = balanced
 // read schedule (tile_bal);  bits 2-4 and 6 are DIAGNOSTIC (tuning builds, wrong results, timing only): 4 = no MFMAs,

@@ -103,7 +103,7 @@ def test_rmsnorm(rows, d):
 @pytest.mark.parametrize("M,N,K", [(2440, 1536, 512), (648, 1024, 1024), (8, 256, 256), (4880, 512, 4096), (328, 8200, 256)])
 def test_gemm_configurations_are_bit_identical(M, N, K):
     """Every tile configuration of both GEMM kernels (8-phase: 320x256, 256x256, 160x256, 320x128 with swapped MFMA operand
-    roles and 8-byte epilogue accesses; 16-wave: BM 128..320) accumulates a K-tile at a time in the same order with the same
+    roles and 16-byte epilogue accesses, both read schedules; 16-wave: BM 128..320) accumulates a K-tile at a time in the same order with the same
     MFMA: the planner's choice never changes a bit of the result.  Ragged last tiles in M and N included."""
     lib = abi.lib()
     g = torch.Generator().manual_seed(M + N + K)
