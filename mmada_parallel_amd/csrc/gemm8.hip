@@ -10,8 +10,10 @@
 //     in registers for two phases) against one W half (FB fragments x 2 k-steps):
 //         P1 (A0,B0)   P2 (A0,B1)   P3 (A1,B1)   P4 (A1,B0)
 //     phase = { LDS-DMA issue for a later K-tile ; ds_read_b128 of ONE operand half ; counted vmcnt ; barrier ;
-//               MFMA cluster ; barrier }.  P1 reads A0, P2 B1, P3 A1 and P4 the NEXT K-tile's B0 (into the W registers P3
-//     released), so no phase has to fetch two halves while its SIMD partner is only 20 MFMAs long.
+//               MFMA cluster ; barrier }.  Balanced schedule (tile_bal: the 256x256 / 160x256 / 320x128 tiles): P1 reads A0,
+//     P2 B1, P3 A1 and P4 the NEXT K-tile's B0 (into the W registers P3 released), so no phase has to fetch two halves
+//     while its SIMD partner is only 20 MFMAs long.  First schedule (tile: the 320x256 tile, whose RESID / QKV builds would
+//     spill inside the loop with the other one): P1 reads A0 and B0, P2 B1, P3 A1, P4 nothing.  launch_epi8 picks.
 //   * the LDS image of a K-tile is cut the same way into four HALF-TILES (A0, A1, B0, B1 = the rows every wave reads for
 //     that half).  A half-tile slot is re-filled two phases after its last ds_read, with the data of the K-tile AFTER next:
 //     four half-tiles (one whole K-tile, up to 72 KiB per CU) are always in flight, each issued at least four phases — one
