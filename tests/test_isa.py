@@ -13,6 +13,8 @@ import isa_check  # noqa: E402
 
 
 def test_gemm8_counted_waits_see_only_lds_dma():
+    """Also: no static LDS, LDS-DMA in the scalar-base form, and (STORE / RESID / SwiGLU builds) nothing but 16-byte stores
+    in the epilogue, fed by v_permlane16_swap."""
     report, errors = isa_check.check_gemm8()
     assert len(report) == 16, report                      # 4 epilogues x 4 tile configurations
     assert not errors, "\n".join(errors)
@@ -21,6 +23,7 @@ def test_gemm8_counted_waits_see_only_lds_dma():
 
 
 def test_attention_matrix_blocks_are_software_pipelined():
+    """Also: no spills, no static LDS, and the per-tile half-row exchange on the VALU (v_permlane32_swap, no ds_bpermute)."""
     report, errors = isa_check.check_attention()
     assert not errors, "\n".join(errors)
     assert report and report[0][2] >= 64

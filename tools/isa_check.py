@@ -11,6 +11,9 @@ hand-written wait must be `vmcnt(0)` (which is exact whatever is queued); a coun
 Also checked: no static LDS (the kernel forms LDS addresses from integers, i.e. assumes its dynamic segment starts at 0),
 and every kernel really uses the LDS-DMA saddr form.
 
+Epilogues of the 8-phase GEMM (STORE / RESID / SwiGLU builds): 16-byte stores only, fed by v_permlane16_swap.  Attention: the
+per-tile half-row maximum is exchanged with v_permlane32_swap (no ds_bpermute inside the loop).
+
 The tensor-parallel pull transport (csrc/tp_comm.hip) must read remote memory with ONE 16-byte system-scope load per
 16 bytes (`global_load_dwordx4 ... sc0 sc1`), never as two 8-byte halves (each would use half of every 64-B fabric
 request and the second would re-request the same lines).
@@ -151,6 +154,17 @@ def check_gemm8(asm=None):
             errors.append(f"{name}: static LDS of {lds} bytes (the kernel assumes its dynamic LDS segment starts at 0)")
         if n_dma == 0 or n_saddr != n_dma:
             errors.append(f"{name}: {n_saddr} of {n_dma} LDS-DMA loads use the scalar-base form")
+        # epilogues of the STORE / RESID / SwiGLU builds (template argument EPI = 0, 1, 2: every wave has the transposed
+        # accumulator): all output goes out as 16-byte stores after a half-row lane exchange — no 2-, 4- or 8-byte store left
+        m_epi = re.search(r"gemm8_kernelILi(\d)E", name)
+        if m_epi and int(m_epi.group(1)) in (0, 1, 2):
+            flat = [x for b in blocks for x in b]
+            narrow = sum(1 for x in flat if re.match(r"global_store_(short|dword|dwordx2)\b", x))
+            wide = sum(1 for x in flat if x.startswith("global_store_dwordx4"))
+            swaps = sum(1 for x in flat if x.startswith("v_permlane16_swap"))
+            if narrow or not wide or not swaps:
+                errors.append(f"{name}: epilogue stores: {wide} x 16 B, {narrow} narrower, {swaps} v_permlane16_swap "
+                              f"(expected 16-byte stores only, fed by the half-row exchange)")
         report.append((name, n_dma, n_wait, n_foreign))
     if not report:
         errors.append("no gemm8 kernel found")
@@ -179,6 +193,12 @@ def check_attention(asm=None):
             errors.append(f"{name}: {n_saddr} of {n_dma} LDS-DMA loads use the scalar-base form")
         if counted < 12:
             errors.append(f"{name}: only {counted} counted lgkmcnt waits: the fragment prefetch was serialised by the compiler")
+        # the half-row maximum of every key tile is exchanged on the VALU (v_permlane32_swap); the only ds_bpermute left is
+        # the one of the final row sum, outside the loop
+        n_swap = sum(1 for ln in lines if ln.strip().startswith("v_permlane32_swap"))
+        n_bperm = sum(1 for ln in lines if ln.strip().startswith("ds_bpermute"))
+        if n_swap < 1 or n_bperm > 1:
+            errors.append(f"{name}: {n_swap} v_permlane32_swap, {n_bperm} ds_bpermute (expected the per-tile exchange on the VALU)")
         report.append((name, n_dma, sum(1 for ln in lines if "v_mfma" in ln), counted))
     if not report:
         errors.append("attn4p kernel not found")
