@@ -1,8 +1,10 @@
 #!/usr/bin/env python
 """Headline benchmark: images/sec of the MMaDA-Parallel 8B parallel text+image sampler on MI355X.
 
-    python bench.py --gpus 1 --steps K --warmup W [--config {0,1,3,4}] [--scaling {weak,strong}]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config {0,1,3,4}] [--scaling {weak,strong}]
+        N = 1, 2, 4, 8 as a PLAIN command: for N > 1 bench.py starts its own N ranks (torch.distributed.run on 127.0.0.1,
+        one rank per GPU over RCCL) and prints rank 0's JSON line as the last line of stdout
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W   (same thing)
 
 --config 1 (default, the headline): one "step" = one complete TI2TI job of BASELINE.json configs[1]: MMaDA-Parallel-A,
   512x512 output, text_steps=128, timesteps=64, cfg_scale=0, cfg_img=4.0, temperature=0, L = 2438 tokens, 256 forwards
@@ -420,6 +422,34 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
     raise SystemExit(f"--config {cfgnum}: only 0, 1 (headline), 3 (M, batch 4) and 4 (A editing, batch 16) have a single-node form")
 
 
+def self_launch(n, script=None, argv=None):
+    """`python bench.py --gpus N ...` without a launcher: re-run this command under torch.distributed.run with N ranks on
+    this node (one rank per GPU over RCCL; rendezvous on 127.0.0.1, a free port).  The ranks' stdout is relayed to stderr
+    except rank 0's JSON line, which is printed as the LAST line of stdout; the exit code is the launcher's (non-zero if no
+    line came back)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), script or os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else list(argv))
+    env = dict(os.environ, MMADA_BENCH_SELF_LAUNCHED="1")
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line_out = None
+    for line in proc.stdout:
+        s = line.strip()
+        if s.startswith('{"metric"') and s.endswith("}"):
+            line_out = s
+        else:
+            sys.stderr.write(line)
+    rc = proc.wait()
+    if line_out is not None:
+        print(line_out, flush=True)
+    return rc if rc else (0 if line_out is not None else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -454,9 +484,11 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus))   # plain `python bench.py --gpus N`: spawn the N ranks ourselves
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N` (bench.py starts its own "
+                 "ranks) or under torch.distributed.run --nproc-per-node N")
     # MMADA_BENCH_ONE_GPU=1 (test rigs with a single GPU): every rank uses cuda:0 and the collective runs over gloo, so
     # the multi-process tensor-parallel path can be exercised end to end; such a line is marked and is not a measurement.
     one_gpu = os.environ.get("MMADA_BENCH_ONE_GPU") == "1"
@@ -519,9 +551,12 @@ def main():
         allv = [None] * world
         dist.all_gather_object(allv, final_ids.tolist())  # all jobs, before the one random fill of the read-out
         ranks_agree = all(a == allv[0] for a in allv) if tp > 1 else None
-    ar_probe = None
+    ar_probe, exposure = None, None
     if use_dist and tp > 1:
         ar_probe = model.collective_probe(L) if hasattr(model, "collective_probe") else None
+        if hasattr(model, "exchange_exposure_probe") and args.config in (0, 1, 4):
+            # the conditional forward of one step (batch = the step's jobs) with and without its 2 x n_layers exchanges
+            exposure = model.exchange_exposure_probe(wl["cpu"]["ids"].repeat(wl["images_per_step"], 1).to(dev))
     comm_error = None
     if getattr(model, "_comm_in_library", False):  # a hand-off of the pull transport timed out: the images are void
         comm_error = model.comm_status()["error"]
@@ -570,8 +605,17 @@ def main():
                        "hipgraph_step": bool(getattr(model, "graph_replays", 0)),
                        "hipgraph_nodes_per_step_kind": {str(k): v for k, v in getattr(model, "graph_nodes", {}).items()} or None,
                        "tp_ranks_agree": ranks_agree, "tp_collective": getattr(model, "tp_collective", None),
+                       # ranks of the RCCL communicators that actually exist in this run: torch.distributed's (control
+                       # plane, codes all-gather) and the library's own (ncclCommCount; created beside the pull transport
+                       # for the probe, or as the data path when the pull transport is not in use)
+                       "rccl_nranks": (dist.get_world_size() if use_dist and dist.get_backend() == "nccl" else 0),
+                       "library_rccl_nranks": model.rccl_nranks() if hasattr(model, "rccl_nranks") else 0,
+                       "launched_by": ("bench.py self-launch -> torch.distributed.run" if os.environ.get("MMADA_BENCH_SELF_LAUNCHED")
+                                       else "torch.distributed.run" if "RANK" in os.environ else "single process"),
                        "tp_comm_error": comm_error, "launch_probe": lprobe,
                        "allreduce_probe": ar_probe,
+                       "exposed_exchange_ms_per_forward": exposure["exposed_exchange_ms_per_forward"] if exposure else None,
+                       "exchange_exposure_probe": exposure,
                        "rocm_smi_during_run": smi.summary() if smi else None,
                        "kernels": kinds},
             "roofline": {"bound": "mfma", "kernel": KIND_NAMES[dom], "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,

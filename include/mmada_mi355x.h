@@ -364,7 +364,10 @@ int mmada_mfma_probe(const void* data, void* sink, int iters, int launches, void
  *   mmada_comm_connect_rccl  RCCL transport (ncclReduceScatter / ncclAllGather issued by the library); unique_id128 from
  *                            mmada_comm_unique_id on rank 0, distributed by the host; librccl_path NULL = "librccl.so"
  *                            (pass the path of the library the process already has loaded, e.g. torch/lib/librccl.so)
- *   mmada_comm_set_mode      switch between connected transports (1 pull, 2 RCCL)
+ *   mmada_comm_set_mode      switch between connected transports (1 pull, 2 RCCL); 3 = DIAGNOSTIC "no exchange": the
+ *                            forward runs its owner-side kernels on this rank's own partial sums only (no peer traffic,
+ *                            no hand-off; wrong values) — bench.py times it to report the exposed exchange time
+ *   mmada_comm_rccl_nranks   ranks of the RCCL communicator this handle created (ncclCommCount), 0 if none
  *   mmada_comm_status        transport in use, sticky error (a peer never arrived within MMADA_TP_TIMEOUT_S, default 20 s:
  *                            the device is never hung, the results are void), whether the counters are fine-grained
  *   mmada_comm_exchange      ONE exchange over the rows of the resident carve with the caller's partials
@@ -377,6 +380,7 @@ int mmada_comm_connect_local(mmada_handle* h, mmada_handle* const* ranks);
 int mmada_comm_unique_id(void* out128, const char* librccl_path);
 int mmada_comm_connect_rccl(mmada_handle* h, const void* unique_id128, const char* librccl_path);
 int mmada_comm_set_mode(mmada_handle* h, int mode);
+int mmada_comm_rccl_nranks(mmada_handle* h);
 /* Hand-off timeout of the pull transport in seconds (<= 0: MMADA_TP_TIMEOUT_S or 20 s); clears a sticky error. */
 int mmada_comm_set_timeout(mmada_handle* h, double seconds);
 int mmada_comm_status(mmada_handle* h, int* mode_out, int* err_out, int* finegrained_out, void* stream);

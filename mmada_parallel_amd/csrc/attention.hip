@@ -453,6 +453,17 @@ __global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
 
 }  // namespace
 
+static int attn4p_set_lds_limit() {
+    MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
+#ifdef MMADA_TUNE
+    MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
+    MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
+    MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
+    MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
+#endif
+    return 0;
+}
+
 static int g_attn_form = -1;  // -1: read MMADA_ATTN_FORM once
 void attention_force_form(int form) { g_attn_form = form; }  // -1: back to MMADA_ATTN_FORM / default  // measurement / test hook: 0 = round-2 issue order, 1 = pipelined matrix blocks
 
@@ -462,10 +473,8 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     if (Lkv % 64 || Lkv < L) return mm_fail("attention: Lkv=%d must be a multiple of 64 and >= L=%d", Lkv, L);
     if (Hq % Hkv) return mm_fail("attention: n_heads %% n_kv_heads != 0");
     if (q_begin < 0 || (q_begin & 31) || q_begin >= Lq_rows) return mm_fail("attention: bad q_begin=%d", q_begin);
-    static bool attr_set[16] = {};
-    if (mm_first_use_on_device(attr_set)) {
-        MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
-    }
+    static MmOncePerDevice attr_set;
+    MM_ONCE_PER_DEVICE(attr_set, MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS)));
     AttnArgs a;
     a.q = q; a.k = k; a.vT = vT; a.out = out;
     a.Hq = Hq; a.Hkv = Hkv; a.L = L; a.Lq_rows = Lq_rows; a.Lkv = Lkv;
@@ -490,16 +499,8 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     }
 #endif
     if (g_attn_form != 0) {
-        static bool attr4[16] = {};
-        if (mm_first_use_on_device(attr4)) {
-            MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
-#ifdef MMADA_TUNE
-            MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
-            MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
-            MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
-            MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn4p_fwd_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS));
-#endif
-        }
+        static MmOncePerDevice attr4;
+        MM_ONCE_PER_DEVICE(attr4, if (attn4p_set_lds_limit()) return 1);
     }
     if (xcd_aware && pairs % 8 == 0) {
         a.xcd_pairs = pairs / 8; a.nq = nq;

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 typedef uint16_t bf16_t;  // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
@@ -68,12 +70,22 @@ MM_DEVICE int vt_key_pos(int l) {
 int mm_fail(const char* fmt, ...);
 
 // Function attributes (the dynamic-LDS limit of a kernel) are per DEVICE: a process that drives several devices (the ranks of
-// a tensor-parallel group as handles of one process) must set them on each.  True the first time a launcher runs on the
-// current device; racing threads at worst set the same attribute twice.
-inline bool mm_first_use_on_device(bool (&seen)[16]) {
+// a tensor-parallel group as handles of one process) must set them on each.  MM_ONCE_PER_DEVICE(once, stmts) runs `stmts`
+// the first time a launcher runs on the current device and marks the device only AFTER every statement succeeded (an
+// MM_CHECK_HIP inside returns from the launcher first, so a failed attribute call is retried by the next launch instead of
+// turning into an LDS-size launch error); host threads driving two handles at worst set the same attribute twice.
+struct MmOncePerDevice {
+    std::atomic<bool> seen[16];
+};
+inline int mm_device_slot() {
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return true;
-    if (seen[dev]) return false;
-    seen[dev] = true;
-    return true;
+    return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) ? dev : -1;
 }
+#define MM_ONCE_PER_DEVICE(once, ...)                                                      \
+    do {                                                                                   \
+        const int _slot = mm_device_slot();                                                \
+        if (_slot < 0 || !(once).seen[_slot].load(std::memory_order_acquire)) {            \
+            __VA_ARGS__;                                                                   \
+            if (_slot >= 0) (once).seen[_slot].store(true, std::memory_order_release);     \
+        }                                                                                  \
+    } while (0)

@@ -156,11 +156,9 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bt_kernel(GemmArgs g) {
 template <int EPI, int BM, int WM, int WN>
 int launch_cfg(const GemmArgs& g, hipStream_t s) {
     constexpr int LDS = Tile<BM, WM, WN>::LDS_BYTES;
-    static bool attr_set = false;
+    static MmOncePerDevice attr_set;
     auto fn = gemm_bt_kernel<EPI, BM, WM, WN>;
-    if (!attr_set) {
-        MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-    }
+    MM_ONCE_PER_DEVICE(attr_set, MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS)));
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
     hipLaunchKernelGGL(fn, dim3(ntm * ntn), dim3(NTHREADS), LDS, s, g);
     MM_CHECK_HIP(hipGetLastError());

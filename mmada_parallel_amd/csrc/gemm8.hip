@@ -361,9 +361,8 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
 template <int EPI, class G>
 int launch_cfg8(const GemmArgs& g, hipStream_t s) {
     auto fn = gemm8_kernel<EPI, G>;
-    static bool attr_set[16] = {};
-    if (mm_first_use_on_device(attr_set))
-        MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+    static MmOncePerDevice attr_set;
+    MM_ONCE_PER_DEVICE(attr_set, MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)));
     const int ntm = (g.M + G::BM - 1) / G::BM, ntn = (g.N + G::BN - 1) / G::BN;
     hipLaunchKernelGGL(fn, dim3(ntm * ntn), dim3(512), G::LDS, s, g);
     MM_CHECK_HIP(hipGetLastError());

@@ -438,13 +438,12 @@ int launch_image_probs(const bf16_t* cond, const bf16_t* ut, const bf16_t* ui, i
                        float cfg_img, bf16_t* probs_out, int32_t* argmax_out, bf16_t* pmax_out, int mvar, hipStream_t s) {
     if (B * N <= 0) return 0;
     if (CB % 8 || CB > 16384) return mm_fail("image_probs: codebook=%d must be a multiple of 8 and <= 16384", CB);
-    static bool attr_set[16] = {};
-    if (mm_first_use_on_device(attr_set)) {
+    static MmOncePerDevice attr_set;
+    MM_ONCE_PER_DEVICE(attr_set,
         MM_CHECK_HIP(hipFuncSetAttribute((const void*)image_probs_kernel<false>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4));
         MM_CHECK_HIP(hipFuncSetAttribute((const void*)image_probs_kernel<true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4));
-    }
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4)));
     if (mvar)
         hipLaunchKernelGGL(image_probs_kernel<true>, dim3(B * N), dim3(TB), (size_t)CB * 4, s, cond, ut, ui, CB, cfg_scale,
                            cfg_img, probs_out, argmax_out, pmax_out);
@@ -460,13 +459,12 @@ int launch_image_commit(int64_t* ids, int B, int L, const int32_t* pos_map, int 
                         int mask_id, int text_vocab, int codebook, int mvar, hipStream_t s) {
     if (B <= 0 || N <= 0) return 0;
     if (N > 8192) return mm_fail("image_commit: N=%d too large", N);
-    static bool attr_set[16] = {};  // N * 8 B of dynamic LDS + the kernel's static LDS: above the 64 KiB default near N = 8192
-    if (mm_first_use_on_device(attr_set)) {
+    static MmOncePerDevice attr_set;  // N * 8 B of dynamic LDS + the kernel's static LDS: above the 64 KiB default near N = 8192
+    MM_ONCE_PER_DEVICE(attr_set,
         MM_CHECK_HIP(hipFuncSetAttribute((const void*)image_commit_kernel<true>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
         MM_CHECK_HIP(hipFuncSetAttribute((const void*)image_commit_kernel<false>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8));
-    }
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 8192 * 8)));
     if (mvar) {
         if (!noise) return mm_fail("image_commit (M variant): the gumbel tensor is required");
         hipLaunchKernelGGL(image_commit_kernel<true>, dim3(B), dim3(1024), (size_t)N * 8, s, ids, L, pos_map, N, sampled_in,

@@ -54,12 +54,14 @@ struct RcclApi {
     ncclResult_t (*ReduceScatter)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;  // optional (reporting only)
 };
 
 }  // namespace
 
 struct TpComm {
-    int mode = 0;  // 0: buffers allocated, not connected; 1: pull over mapped peer buffers; 2: RCCL
+    int mode = 0;  // 0: buffers allocated, not connected; 1: pull over mapped peer buffers; 2: RCCL;
+                   // 3: DIAGNOSTIC "no exchange" (owner-side kernel on this rank's own partial only: wrong values, timing only)
     int rank = 0, size = 1, max_rows = 0, d = 0;
     bf16_t* part = nullptr;    // [max_rows + 8*size, d]  published: this rank's partial of the row-parallel GEMM
     bf16_t* hn_pub = nullptr;  // [max_rows + 8*size, d]  published: normalised rows this rank owns (at their global row)
@@ -370,6 +372,12 @@ int exchange(mmada_handle* h, const Slice& sl, const bf16_t* norm_w, hipStream_t
         MM_CHECK_HIP(hipGetLastError());
         return 0;
     }
+    if (c->mode == 3) {  // diagnostic: the forward without its exchange (bench.py: exposed exchange time = real - this)
+        a.nsrc = 1; a.presum = c->part + (size_t)sl.r0 * d;
+        if (own > 0) hipLaunchKernelGGL(tp_reduce_norm_kernel<0>, dim3((own + 3) / 4), dim3(256), 0, s, a);
+        MM_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (c->mode == 2) {
         const size_t cnt = (size_t)sl.slice * d;
         ncclResult_t r = c->nccl.ReduceScatter(c->part + (size_t)sl.m0 * d, c->rs_tmp, cnt, ncclBfloat16, ncclSum, c->comm, s);
@@ -405,6 +413,7 @@ int load_rccl(RcclApi* api, const char* path) {
     LOAD(AllGather, "ncclAllGather");
     LOAD(GetErrorString, "ncclGetErrorString");
 #undef LOAD
+    api->CommCount = (decltype(api->CommCount))dlsym(api->dl, "ncclCommCount");
     return 0;
 }
 
@@ -509,7 +518,7 @@ int tp_forward_body(mmada_handle* h, hipStream_t s) {
 // Residual stream of every owner -> full [M, d] (parity taps; the forward itself never moves the residual stream)
 int tp_gather_stream(mmada_handle* h, bf16_t* full_out, hipStream_t s) {
     TpComm* c = h->tp;
-    if (!c || c->mode == 0) return mm_fail("tp_gather_stream: no transport connected");
+    if (!c || c->mode == 0 || c->mode == 3) return mm_fail("tp_gather_stream: no transport connected (or the no-exchange diagnostic is on)");
     const int d = h->cfg.d_model, M = h->M;
     const int nch = (c->chunks >= 2 && M >= 4 * 8 * c->size) ? 2 : 1;
     for (int k = 0; k < nch; ++k) {
@@ -721,9 +730,18 @@ int mmada_comm_set_mode(mmada_handle* h, int mode) {
     const int other = c->rank == 0 ? 1 : 0;
     if (mode == 1 && !c->peers.ctr[other]) return mm_fail("mmada_comm_set_mode: the pull transport was never connected");
     if (mode == 2 && !c->comm) return mm_fail("mmada_comm_set_mode: the RCCL transport was never connected");
-    if (mode != 1 && mode != 2) return mm_fail("mmada_comm_set_mode: mode must be 1 (pull) or 2 (RCCL)");
+    if (mode == 3 && c->mode == 0) return mm_fail("mmada_comm_set_mode: connect a transport before the no-exchange diagnostic");
+    if (mode < 1 || mode > 3) return mm_fail("mmada_comm_set_mode: mode must be 1 (pull), 2 (RCCL) or 3 (diagnostic: no exchange)");
     c->mode = mode;
     return 0;
+}
+
+/* Ranks of the RCCL communicator this handle created (ncclCommCount), 0 when none was created. */
+int mmada_comm_rccl_nranks(mmada_handle* h) {
+    if (!h || !h->tp || !h->tp->comm) return 0;
+    int n = 0;
+    if (h->tp->nccl.CommCount && h->tp->nccl.CommCount(h->tp->comm, &n) == ncclSuccess) return n;
+    return h->tp->size;  // a librccl without ncclCommCount: the size the communicator was initialised with
 }
 
 void* mmada_comm_part_ptr(mmada_handle* h) { return h && h->tp ? (void*)h->tp->part : nullptr; }
@@ -746,7 +764,7 @@ int mmada_comm_exchange(mmada_handle* h, const void* norm_w, void* stream) {
  * rows: device int32 [B*T] = b*L + text_start + t.  scratch: device, >= B*T*16 bytes (receives conf f64 / x0 i32). */
 int mmada_text_select_tp(mmada_handle* h, const int32_t* rows, int B, int T, int64_t* ids, int L, int text_start,
                          const int32_t* k, void* scratch, void* stream) {
-    if (!h || !h->tp || h->tp->mode == 0) return mm_fail("mmada_text_select_tp: no tensor-parallel transport connected");
+    if (!h || !h->tp || h->tp->mode == 0 || h->tp->mode == 3) return mm_fail("mmada_text_select_tp: no tensor-parallel transport connected");
     if (!h->xn_is_final || h->M == 0) return mm_fail("mmada_text_select_tp: no tensor-parallel forward resident");
     if (!rows || !ids || !k || !scratch) return mm_fail("mmada_text_select_tp: null argument");
     TpComm* c = h->tp;

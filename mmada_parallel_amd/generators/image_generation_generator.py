@@ -21,6 +21,7 @@ import torch
 
 from .. import abi
 from ..model import LLaDAForMultiModalGeneration
+from .parallel_generator import check_tp_exchange
 
 
 def cosine_schedule(t: torch.Tensor) -> torch.Tensor:
@@ -167,5 +168,6 @@ def generate_image(
         if debug:
             print(f"[generate_image] step {step}: unknown {n_unknown} -> keep {int(keep[step])}")
 
+    check_tp_exchange(model)   # tensor parallel: a timed-out hand-off raises instead of returning void tokens
     vq_ids = x[0, code_start:-2]                                       # :239-241
     return vq_ids[vq_ids != newline_id].view(1, seq_len)

@@ -18,7 +18,7 @@ import torch
 
 from .. import abi
 from ..model import LLaDAForMultiModalGeneration
-from .parallel_generator import mask_len_schedule
+from .parallel_generator import check_tp_exchange, mask_len_schedule
 
 
 def cosine_schedule(t):
@@ -170,4 +170,5 @@ def interleave_generate(
                                                p_c.data_ptr(), gumbel.data_ptr(), float(temperature),
                                                mlen_dev[i:i + 1].data_ptr(), text_vocab, st), "mmada_image_commit_m")
 
+    check_tp_exchange(model)   # tensor parallel: a timed-out hand-off raises instead of returning void tokens
     return sampled_ids, ids[:, text_start:]

@@ -22,6 +22,7 @@ import torch
 from .. import abi
 from ..model import LLaDAForMultiModalGeneration
 from .interleave_generator import TorchRng, get_num_transfer_tokens
+from .parallel_generator import check_tp_exchange
 
 
 @torch.no_grad()
@@ -94,6 +95,7 @@ def mmu_generate(model, idx=None, input_embeddings=None, max_new_tokens=128, ste
             last = start + BL - 1
             if last < L and bool((x[:, last] == eot_token).all()):
                 break
+    check_tp_exchange(model)   # tensor parallel: a timed-out hand-off raises instead of returning void tokens
     return x
 
 

@@ -450,4 +450,6 @@ def generate_ti2ti_stepwise(
             if step >= text_steps:
                 return
             show = step % 5 == 0 or info["image_step"] or step == text_steps - 1
+            if step == text_steps - 1:
+                check_tp_exchange(model)   # the last yield is the result: raise rather than hand out void tokens
             yield step + 1, ids, info["sampled"], show

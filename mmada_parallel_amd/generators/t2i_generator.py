@@ -18,7 +18,7 @@ import torch
 from .. import abi
 from ..model import LLaDAForMultiModalGeneration
 from .interleave_generator import TorchRng, _log, cosine_schedule
-from .parallel_generator import mask_len_schedule
+from .parallel_generator import check_tp_exchange, mask_len_schedule
 
 
 def _t2i_steps(
@@ -113,6 +113,7 @@ def t2i_generate(model, input_ids=None, uncond_input_ids=None, attention_mask=No
                                          temperature, timesteps, guidance_scale, noise_schedule, generator, config, seq_len,
                                          mask_token_id, resolution, codebook_size, rng, trace, **kwargs):
         pass
+    check_tp_exchange(model)   # tensor parallel: a timed-out hand-off raises instead of returning void tokens
     return sampled_ids
 
 
@@ -129,6 +130,8 @@ def t2i_generate_decoding_stepwise(model, input_ids=None, uncond_input_ids=None,
     for step, sampled_ids in _t2i_steps(model, input_ids, uncond_input_ids, attention_mask, uncond_attention_mask,
                                         temperature, timesteps, guidance_scale, noise_schedule, generator, config, seq_len,
                                         mask_token_id, resolution, codebook_size, rng, None, **kwargs):
+        if step == timesteps - 1:
+            check_tp_exchange(model)
         cur = torch.clamp(sampled_ids.clone(), 0, 8192 - 1)                         # :839-840 (constant as in the reference)
         images = torch.clamp((vq_model.decode_code(cur) + 1.0) / 2.0, min=0.0, max=1.0) * 255.0
         images = images.permute(0, 2, 3, 1).cpu().numpy().astype("uint8")

@@ -544,6 +544,49 @@ class LLaDAForMultiModalGeneration:
                 abi.check(self._lib.mmada_comm_set_mode(self._handle, 1), "mmada_comm_set_mode")
         return out
 
+    def rccl_nranks(self) -> int:
+        """Ranks of the RCCL communicator the LIBRARY created (ncclCommCount), 0 when it holds none."""
+        return int(self._lib.mmada_comm_rccl_nranks(self._handle)) if self._comm_in_library or getattr(self, "_rccl_also", False) else 0
+
+    def exchange_exposure_probe(self, input_ids: torch.Tensor, reps: int = 3):
+        """Outside any timed region: wall time of one tensor-parallel forward with its exchanges and of the same forward
+        with the library's "no exchange" diagnostic (mmada_comm_set_mode 3: identical GEMM / attention / owner-side kernels,
+        no peer traffic, no hand-off; the values are wrong, only the time is used).  The difference is what the exchanges
+        cost the forward AFTER the two-chunk overlap: the exposed exchange time.  Every rank must call it."""
+        if not self._comm_in_library or self.tp_size == 1:
+            return None
+        import time
+
+        import torch.distributed as dist
+
+        real_mode = {"pull": 1, "rccl": 2}[self.tp_collective]
+
+        def timed(mode):
+            abi.check(self._lib.mmada_comm_set_mode(self._handle, mode), "mmada_comm_set_mode")
+            ts = []
+            try:
+                for i in range(reps + 1):
+                    if dist.is_initialized():
+                        dist.barrier()
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    self.forward_body(input_ids)
+                    torch.cuda.synchronize()
+                    if i:   # the first call of a mode is a warm-up
+                        ts.append((time.perf_counter() - t0) * 1e3)
+            finally:
+                abi.check(self._lib.mmada_comm_set_mode(self._handle, real_mode), "mmada_comm_set_mode")
+            return sorted(ts)[len(ts) // 2]
+
+        with_x = timed(real_mode)
+        without = timed(3)
+        with_x2 = timed(real_mode)
+        ms = min(with_x, with_x2)
+        return {"forward_ms_with_exchange": ms, "forward_ms_no_exchange_diagnostic": without,
+                "exposed_exchange_ms_per_forward": ms - without, "exchanges_per_forward": 2 * self.config.n_layers,
+                "batch": int(input_ids.shape[0]), "what": "median wall time of a synchronised forward_body, real transport vs "
+                "mmada_comm_set_mode(3) (owner-side kernels on the rank's own partials only, no peer traffic)"}
+
     def vocab_parallel_head(self) -> bool:
         """True when the text step can run on vocabulary slices of the LM head (library transport connected)."""
         return self._comm_in_library and os.environ.get("MMADA_TP_REPLICATED_HEAD") != "1"

@@ -730,32 +730,47 @@ def test_m_t2i_generate_stub_trajectory_bit_exact(tiny_model, name):
 
 
 # ------------------------------------------------------------------ multi-process tensor parallel, end to end (one GPU)
-@pytest.mark.parametrize("world", [2, 4, 8])
-def test_bench_multi_rank_tensor_parallel_on_one_gpu(world):
-    """bench.py's N-rank path (one process per rank, TP = N, N jobs, micro-batched async all-reduce) launched exactly as
-    the driver launches it, except that all ranks share cuda:0 and the collective runs over gloo (MMADA_BENCH_ONE_GPU=1):
-    every rank must finish, sample identical tokens (tp_ranks_agree) and rank 0 must print one JSON line."""
+@pytest.mark.parametrize("world,plain", [(2, True), (4, False), (8, True)])
+def test_bench_multi_rank_tensor_parallel_on_one_gpu(world, plain):
+    """bench.py's N-rank path (one process per rank, TP = N, N jobs) launched as the driver launches it — as the PLAIN command
+    `python bench.py --gpus N ...` (bench.py starts its own ranks under torch.distributed.run) or under torch.distributed.run
+    directly — except that all ranks share cuda:0 and the control plane runs over gloo (MMADA_BENCH_ONE_GPU=1): every rank
+    must finish, sample identical tokens (tp_ranks_agree) and the ONE JSON line must be the last line of stdout."""
     import json
     import subprocess
     import sys
 
     env = dict(os.environ, MMADA_BENCH_ONE_GPU="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
-           "127.0.0.1", "--master-port", str(29600 + world), os.path.join(ROOT, "bench.py"), "--gpus", str(world),
-           "--steps", "1", "--warmup", "0", "--layers", "2", "--text-steps", "8", "--timesteps", "4", "--no-cpu-baseline"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    tail = ["--gpus", str(world), "--steps", "1", "--warmup", "0", "--layers", "2", "--text-steps", "8", "--timesteps", "4",
+            "--no-cpu-baseline"]
+    if plain:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr",
+               "127.0.0.1", "--master-port", str(29600 + world), os.path.join(ROOT, "bench.py")] + tail
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
+    if plain:
+        assert p.stdout.strip().splitlines()[-1] == lines[0]   # the line is the LAST line of stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == world and out["config"]["parallelism"] == f"tp{world}" and out["config"]["global_batch"] == world
     assert out["config"]["tp_ranks_agree"] is True
     assert out["value"] > 0 and "REDUCED" in out["config"]["workload"]
+    assert ("self-launch" in out["config"]["launched_by"]) == plain
     # the exchange ran inside the library over hipIpc-mapped peer buffers (gloo only carried the handles), passed its
     # self-test on every rank, and no hand-off timed out
     assert out["config"]["tp_collective"] == "pull", out["config"]["tp_collective"]
     probe = out["config"]["allreduce_probe"]
     assert probe and probe["status"]["error"] == 0 and probe["status"]["mode"] == "pull"
+    # one rank per device is what RCCL needs: on the one-GPU rig no RCCL communicator exists, and the line says so
+    assert out["config"]["rccl_nranks"] == 0 and out["config"]["library_rccl_nranks"] == 0
+    ex = out["config"]["exchange_exposure_probe"]
+    assert ex and ex["forward_ms_with_exchange"] > 0 and ex["forward_ms_no_exchange_diagnostic"] > 0
+    assert out["config"]["exposed_exchange_ms_per_forward"] == ex["exposed_exchange_ms_per_forward"]
 
 
 # ------------------------------------------------------------------------------- consumed-row window of the last block

@@ -280,3 +280,40 @@ def test_gemm8_schedule(na0, na1, nb, balanced):
                 assert ph - landed[(n, t)] >= 1, f"RAW: {n}{t} read in the phase of its wait"
                 last_read[(t & 1, n)] = ph
         assert not fifo
+
+
+def test_bench_self_launch_relays_the_line_and_the_exit_code(tmp_path):
+    """`python bench.py --gpus N` as a plain command: bench.self_launch runs the script under torch.distributed.run with N ranks
+    (gloo here), relays everything but rank 0's JSON line to stderr, prints that line LAST on stdout, and returns the
+    launcher's exit code (non-zero when a rank fails or no line came back)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ok = tmp_path / "ranks_ok.py"
+    ok.write_text(
+        "import os, sys, json\n"
+        "import torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "print('noise from rank', os.environ['RANK'], flush=True)\n"
+        "dist.barrier()\n"
+        "if dist.get_rank() == 0:\n"
+        "    print(json.dumps({'metric': 'm', 'n_gpus': dist.get_world_size(), 'argv': sys.argv[1:]}), flush=True)\n"
+        "dist.barrier()\n"
+        "print('late noise', flush=True)\n"
+        "dist.destroy_process_group()\n")
+    bad = tmp_path / "ranks_bad.py"
+    bad.write_text("import os, sys\nsys.exit(3 if os.environ['RANK'] == '1' else 0)\n")
+    drv = ("import sys; sys.path.insert(0, %r); import bench; "
+           "sys.exit(bench.self_launch(2, script=sys.argv[1], argv=['--gpus', '2', '--steps', '1']))" % root)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, "-c", drv, str(ok)], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-1500:]
+    out_lines = p.stdout.strip().splitlines()
+    assert len(out_lines) == 1 and "noise" in p.stderr
+    import json
+
+    line = json.loads(out_lines[-1])
+    assert line["n_gpus"] == 2 and line["argv"] == ["--gpus", "2", "--steps", "1"]
+    p = subprocess.run([sys.executable, "-c", drv, str(bad)], capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode != 0 and p.stdout.strip() == ""
