@@ -12,8 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_NAME = "libmmada_mi355x.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
-SOURCES = ["gemm.hip", "gemm8.hip", "attention.hip", "elementwise.hip", "sampler.hip", "vq_decoder.hip", "graph.hip", "tp_comm.hip", "probe.hip", "api.hip"]
-HEADERS = ["common.h", "kernels.h", "gemm_epilogue.h", "handle.h", os.path.join("..", "..", "include", "mmada_mi355x.h")]
+SOURCES = ["gemm.hip", "gemm8.hip", "attention.hip", "attention64.hip", "elementwise.hip", "sampler.hip", "vq_decoder.hip", "graph.hip", "tp_comm.hip", "probe.hip", "api.hip"]
+HEADERS = ["common.h", "kernels.h", "gemm_epilogue.h", "handle.h", "attention.h", os.path.join("..", "..", "include", "mmada_mi355x.h")]
 
 
 def _hipcc() -> str:

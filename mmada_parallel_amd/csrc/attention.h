@@ -1,0 +1,63 @@
+// attention.h — what the attention kernels of attention.hip (4 waves x 32 query rows) and attention64.hip (4 waves x 64
+// query rows, one wave per SIMD) share: tile constants, launch arguments, single-instruction maxima, LDS addressing.
+#pragma once
+#include <cstdlib>
+#include <type_traits>
+
+#include "kernels.h"
+
+namespace attn_detail {
+
+constexpr int QB = 128;  // query rows per workgroup
+constexpr int KB = 64;   // keys per tile
+constexpr int TILE_BYTES = KB * 128 * 2;  // 16 KiB (K tile == vT tile)
+constexpr int ATT_LDS = 4 * TILE_BYTES;   // 2 stages x (K + vT)
+constexpr float DEFER_LOG2 = 4.0f;
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// 3-input / 2-input fp32 max as single instructions: hipcc wraps fmaxf() on MFMA outputs in canonicalising
+// v_max_f32 x,x (one extra VALU op per score); scores are never signalling NaNs here.
+MM_DEVICE float max3f(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+MM_DEVICE float fmax_nc(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+struct AttnArgs {
+    const bf16_t* q;
+    const bf16_t* k;
+    const bf16_t* vT;
+    bf16_t* out;
+    int Hq, Hkv, L, Lq_rows, Lkv, out_rows_per_batch, ld_out;
+    int q_begin;  // first query row (multiple of 32); output row of query r is b*out_rows_per_batch + r - q_begin
+    int Lq_alloc; // rows per (batch, head) of q: Lkv, or the compact length of a cache step's queries
+    float scale_log2e;
+    int xcd_pairs, nq;  // XCD-aware 1-D grid: (batch, head) pairs per XCD and query tiles per pair (0: plain 3-D grid)
+    // attn64 only (attn64_plan): the first n_full workgroups run full passes (256 query rows, `full_per_pair` per (batch,
+    // head) pair, q-blocks [0, 8 * full_per_pair)), the others half passes (128 rows, `half_per_pair` per pair)
+    int n_full, full_per_pair, half_per_pair;
+};
+
+// The kernel owns its whole LDS allocation and has no static __shared__ object: the dynamic segment starts at LDS address 0
+// (tests/test_isa.py), so LDS addresses are plain integers — no "base + offset" VALU add per access.
+typedef __attribute__((address_space(3))) const bf16x8* lds_frag_ptr;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+#pragma clang diagnostic ignored "-Wint-to-void-pointer-cast"
+MM_DEVICE bf16x8 lds_frag(int byte_off) { return *(lds_frag_ptr)(uint32_t)byte_off; }
+MM_DEVICE lptr_t lds_at(int byte_off) { return (lptr_t)(uint32_t)byte_off; }
+#pragma clang diagnostic pop
+
+#define A8_SB() __builtin_amdgcn_sched_barrier(0)
+
+}  // namespace attn_detail
+
+// attention64.hip
+int launch_attention64(attn_detail::AttnArgs a, int B, hipStream_t s, int var = 0);

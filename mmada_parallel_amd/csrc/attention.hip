@@ -16,46 +16,11 @@
 // K/V tiles (64 keys) arrive by LDS-DMA (global_load_lds_dwordx4) into a 2-stage ring, one barrier per tile; the
 // 16-B-chunk XOR swizzle is applied to the DMA source address and to the ds_read_b128 address (conflict-free).
 // The O rescale is skipped while the running max grows by less than 2^DEFER_LOG2 (P stays <= 2^DEFER_LOG2).
-#include <cstdlib>
-#include <type_traits>
-
-#include "kernels.h"
+#include "attention.h"
 
 namespace {
 
-constexpr int QB = 128;  // query rows per workgroup
-constexpr int KB = 64;   // keys per tile
-constexpr int TILE_BYTES = KB * 128 * 2;  // 16 KiB (K tile == vT tile)
-constexpr int ATT_LDS = 4 * TILE_BYTES;   // 2 stages x (K + vT)
-constexpr float DEFER_LOG2 = 4.0f;
-
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-// 3-input / 2-input fp32 max as single instructions: hipcc wraps fmaxf() on MFMA outputs in canonicalising
-// v_max_f32 x,x (one extra VALU op per score); scores are never signalling NaNs here.
-MM_DEVICE float max3f(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-MM_DEVICE float fmax_nc(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-
-struct AttnArgs {
-    const bf16_t* q;
-    const bf16_t* k;
-    const bf16_t* vT;
-    bf16_t* out;
-    int Hq, Hkv, L, Lq_rows, Lkv, out_rows_per_batch, ld_out;
-    int q_begin;  // first query row (multiple of 32); output row of query r is b*out_rows_per_batch + r - q_begin
-    int Lq_alloc; // rows per (batch, head) of q: Lkv, or the compact length of a cache step's queries
-    float scale_log2e;
-    int xcd_pairs, nq;  // XCD-aware 1-D grid: (batch, head) pairs per XCD and query tiles per pair (0: plain 3-D grid)
-};
+using namespace attn_detail;
 
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -221,17 +186,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnArgs a) {
     }
 }
 
-// The kernel owns its whole LDS allocation and has no static __shared__ object: the dynamic segment starts at LDS address 0
-// (tests/test_isa.py), so LDS addresses are plain integers — no "base + offset" VALU add per access.
-typedef __attribute__((address_space(3))) const bf16x8* lds_frag_ptr;
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
-#pragma clang diagnostic ignored "-Wint-to-void-pointer-cast"
-MM_DEVICE bf16x8 lds_frag(int byte_off) { return *(lds_frag_ptr)(uint32_t)byte_off; }
-MM_DEVICE lptr_t lds_at(int byte_off) { return (lptr_t)(uint32_t)byte_off; }
-#pragma clang diagnostic pop
-
-#define A8_SB() __builtin_amdgcn_sched_barrier(0)
 
 // ---- 4-wave kernel, pipelined matrix blocks (round 3) ---------------------------------------------------------------
 // The arithmetic and its order are those of attn_fwd_kernel (bit-identical output); what changes is how the two matrix
@@ -451,6 +405,7 @@ __global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
     }
 }
 
+
 }  // namespace
 
 static int attn4p_set_lds_limit() {
@@ -485,9 +440,11 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     const int pairs = Hq * B;
     static const bool xcd_aware = [] { const char* e = getenv("MMADA_ATTN_XCD"); return !(e && e[0] == '0'); }();
     if (g_attn_form < 0) {
-        const char* e = getenv("MMADA_ATTN_FORM");  // 0: round-2 issue order; 1 (default): pipelined matrix blocks
+        const char* e = getenv("MMADA_ATTN_FORM");  // 0: round-2 issue order; 1: pipelined matrix blocks; 2: attention64.hip
         g_attn_form = e ? atoi(e) : 1;
     }
+    // 2: 64 query rows per wave, one wave per SIMD (attention64.hip); 20 + v: its diagnostic variant v (tuning builds)
+    if (g_attn_form == 2 || g_attn_form >= 20) return launch_attention64(a, B, s, g_attn_form == 2 ? 0 : g_attn_form - 20);
     const int nq = (Lq_rows - q_begin + QB - 1) / QB;
     auto fn = g_attn_form == 1 ? attn4p_fwd_kernel<0> : attn_fwd_kernel;
 #ifdef MMADA_TUNE

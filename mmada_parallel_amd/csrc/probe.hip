@@ -48,21 +48,105 @@ __global__ __launch_bounds__(PROBE_WAVES * 64, 2) void mfma_probe_kernel(const b
     if (t == 123.456f) sink[0] = t;  // keeps the accumulators live; practically never true
 }
 
+
+// Variants (mmada_set_option("probe_variant", v); measurement only): v & 1 = v_mfma_f32_32x32x16_bf16 instead of the
+// production 16x16x32 (twice the flops per instruction, half the operand-register reads per flop: does the part hold a higher
+// clock on it at its power limit?), v & 2 = four waves per CU (one per SIMD) instead of eight.
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 2) void mfma_probe32_kernel(const bf16_t* data, int iters, float* sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bf16x8* src = (const bf16x8*)data + (size_t)((blockIdx.x % 64) * PROBE_WAVES + wave) * 16 * 64 + lane;
+    bf16x8 a[2][2], b[2][4];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[s][i] = src[(s * 8 + i) * 64];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) b[s][i] = src[(s * 8 + 4 + i) * 64];
+    }
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 123.456f) sink[0] = t;
+}
+
+__global__ __launch_bounds__(4 * 64, 2) void mfma_probe16w4_kernel(const bf16_t* data, int iters, float* sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bf16x8* src = (const bf16x8*)data + (size_t)((blockIdx.x % 64) * PROBE_WAVES + wave) * 16 * 64 + lane;
+    bf16x8 a[2][PROBE_FRAGS], b[2][PROBE_FRAGS];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int i = 0; i < PROBE_FRAGS; ++i) {
+            a[s][i] = src[(s * 8 + i) * 64];
+            b[s][i] = src[(s * 8 + 4 + i) * 64];
+        }
+    f32x4 acc[PROBE_FRAGS][PROBE_FRAGS];
+#pragma unroll
+    for (int i = 0; i < PROBE_FRAGS; ++i)
+#pragma unroll
+        for (int j = 0; j < PROBE_FRAGS; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int i = 0; i < PROBE_FRAGS; ++i)
+#pragma unroll
+                for (int j = 0; j < PROBE_FRAGS; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[s][i], b[s][j], acc[i][j], 0, 0, 0);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < PROBE_FRAGS; ++i)
+#pragma unroll
+        for (int j = 0; j < PROBE_FRAGS; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 123.456f) sink[0] = t;
+}
+
 }  // namespace
 
 // data: >= 64 * 8 * 16 * 64 * 16 bytes (8 MiB) of bf16 values the caller filled (random: never zeros — see above).
 // Runs `launches` back-to-back launches of `iters` iterations on `stream` and returns the achieved dense TFLOP/s.
+static int g_probe_variant = 0;
+void mfma_probe_set_variant(int v) { g_probe_variant = v & 3; }
+
 int launch_mfma_probe(const bf16_t* data, float* sink, int iters, int launches, hipStream_t s, double* tflops_out, double* ms_out) {
+    typedef void (*probe_fn)(const bf16_t*, int, float*);
+    const int v = g_probe_variant;
+    const probe_fn fn = v == 0 ? (probe_fn)mfma_probe_kernel : v == 1 ? (probe_fn)mfma_probe32_kernel<8>
+                      : v == 2 ? (probe_fn)mfma_probe16w4_kernel : (probe_fn)mfma_probe32_kernel<4>;
+    const int waves = (v & 2) ? 4 : PROBE_WAVES;
+    const double flops_per_iter = (v & 1) ? 16 * (2.0 * 32 * 32 * 16) : MFMA_PER_ITER * (2.0 * 16 * 16 * 32);
     int dev = 0, cus = 0;
     MM_CHECK_HIP(hipGetDevice(&dev));
     MM_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     hipEvent_t e0, e1;
     MM_CHECK_HIP(hipEventCreate(&e0));
     MM_CHECK_HIP(hipEventCreate(&e1));
-    hipLaunchKernelGGL(mfma_probe_kernel, dim3(cus), dim3(PROBE_WAVES * 64), 0, s, data, 64, sink);  // warm (code, clocks)
+    hipLaunchKernelGGL(fn, dim3(cus), dim3(waves * 64), 0, s, data, 64, sink);  // warm (code, clocks)
     MM_CHECK_HIP(hipEventRecord(e0, s));
     for (int i = 0; i < launches; ++i)
-        hipLaunchKernelGGL(mfma_probe_kernel, dim3(cus), dim3(PROBE_WAVES * 64), 0, s, data, iters, sink);
+        hipLaunchKernelGGL(fn, dim3(cus), dim3(waves * 64), 0, s, data, iters, sink);
     MM_CHECK_HIP(hipEventRecord(e1, s));
     MM_CHECK_HIP(hipGetLastError());
     MM_CHECK_HIP(hipEventSynchronize(e1));
@@ -70,7 +154,7 @@ int launch_mfma_probe(const bf16_t* data, float* sink, int iters, int launches, 
     MM_CHECK_HIP(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    const double flops = (double)launches * cus * PROBE_WAVES * (double)iters * MFMA_PER_ITER * (2.0 * 16 * 16 * 32);
+    const double flops = (double)launches * cus * waves * (double)iters * flops_per_iter;
     if (tflops_out) *tflops_out = flops / (ms * 1e-3) / 1e12;
     if (ms_out) *ms_out = ms;
     return 0;

@@ -140,7 +140,7 @@ def test_attention_forms_are_bit_identical(handle, B, H, Hkv, L):
     outs = []
     lib = abi.lib()
     try:
-        for form in (0, 1):
+        for form in (0, 1, 2):
             abi.check(lib.mmada_set_option(b"attention_form", form), "set_option")
             out = torch.full((B, L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
             abi.check(lib.mmada_sdpa(handle, q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, H, Hkv, L, st()), "sdpa")
@@ -148,8 +148,9 @@ def test_attention_forms_are_bit_identical(handle, B, H, Hkv, L):
             outs.append(out)
     finally:
         lib.mmada_set_option(b"attention_form", -1)
-    assert torch.isfinite(outs[1].float()).all()
+    assert torch.isfinite(outs[1].float()).all() and torch.isfinite(outs[2].float()).all()
     assert torch.equal(outs[0], outs[1]), f"{int((outs[0] != outs[1]).sum())} elements differ"
+    assert torch.equal(outs[0], outs[2]), f"attention64: {int((outs[0] != outs[2]).sum())} elements differ"
 
 
 @pytest.mark.parametrize("B,H,Hkv,L", [(1, 2, 2, 70), (2, 2, 1, 333), (1, 4, 4, 1000), (1, 2, 2, 64), (1, 1, 1, 1),

@@ -34,9 +34,9 @@ def main():
                     "(11: no soft-max, 12: no MFMA, 13: no tile barrier — DIAGNOSTIC, wrong results; 14: static priority)")
     args = ap.parse_args()
     forms = [int(f) for f in args.forms.split(",")]
-    if max(forms) > 1:
-        from tools.tune.build_tune import build_product_tune
-        os.environ["MMADA_MI355X_LIB"] = build_product_tune()
+    if max(forms) > 2:   # diagnostic variants live in the -DMMADA_TUNE build (prebuilt copies travel with the snapshot)
+        from tools.tune.build_tune import PRODUCT_TUNE_LIB, build_product_tune
+        os.environ["MMADA_MI355X_LIB"] = PRODUCT_TUNE_LIB if os.environ.get("MMADA_TUNE_PREBUILT") == "1" and os.path.exists(PRODUCT_TUNE_LIB) else build_product_tune()
     lib = abi.lib()
     cfg = synth.CFG_8B
     c = abi.MmadaCfg(d_model=cfg["d_model"], n_layers=1, n_heads=32, n_kv_heads=32, head_dim=128, mlp_hidden=12288,
@@ -72,8 +72,9 @@ def main():
             torch.cuda.synchronize()
             ms[form].append(e0.elapsed_time(e1) / args.iters)
     lib.mmada_set_option(b"attention_form", -1)
-    names = {0: "round-2 issue order", 1: "pipelined matrix blocks", 11: "DIAG no soft-max", 12: "DIAG no MFMA", 13: "DIAG no barrier",
-             14: "static priority, second workgroup"}
+    names = {0: "round-2 issue order", 1: "pipelined matrix blocks", 2: "attention64: 64 rows per wave, one wave per SIMD", 11: "DIAG no soft-max", 12: "DIAG no MFMA", 13: "DIAG no barrier",
+             14: "static priority, second workgroup", 21: "attn64 DIAG no LDS-DMA", 22: "attn64 DIAG no exponentials",
+             24: "attn64 DIAG no fragment reads", 28: "attn64 DIAG no MFMA", 27: "attn64 DIAG MFMAs only", 34: "attn64 DIAG LDS-DMA only"}
     for form in forms:
         t = sorted(ms[form])[len(ms[form]) // 2]
         print(f"B={B} L={L} form {form} ({names.get(form, '?')}): median {t * 1e3:.1f} us per "
