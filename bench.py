@@ -289,7 +289,10 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
         mine = slice(rank * (B // tp), (rank + 1) * (B // tp)) if share else slice(0, B)
 
         def run():
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]   # read after the timed region (no sync here)
+            ev[0].record()
             codes = vq_model.quantize(vq_model.encode(pixels[mine]).latents)[2][2].view(-1, n_in)   # encode_img_with_breaks
+            ev[1].record()
             if share:
                 import torch.distributed as dist
 
@@ -310,7 +313,10 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
                                           uncon_image=job["uncon_image"], return_state=True)
             # decode_vq_to_image; the one position the schedule leaves masked is a random code in the reference (A.1)
             out_codes = (final[mine][:, out_pos] - synth.TEXT_VOCAB).clamp(0, CB - 1).view(-1, grid, grid).to(dev)
+            ev[2].record()
             state["pixels"] = vq_model.decode(out_codes, force_not_quantize=True).sample.clip(0, 1)
+            ev[3].record()
+            state.setdefault("vq_events", []).append(ev)
             state["final"] = final
             return final
 
@@ -578,6 +584,11 @@ def main():
     if rank == 0 and not args.no_probe:
         probe = attainable_probe(lib, dev, local if not one_gpu else 0)
 
+    vq_ms = None
+    if wl["state"].get("vq_events"):   # tokenizer share of the step (A: diffusers VQModel restatement, parity unpinned)
+        torch.cuda.synchronize()
+        evs = wl["state"]["vq_events"][-args.steps:]
+        vq_ms = (sum(e[0].elapsed_time(e[1]) for e in evs) / len(evs), sum(e[2].elapsed_time(e[3]) for e in evs) / len(evs))
     if rank == 0:
         fl_img = wl["flops_per_image"]
         # tp: ONE group holds all jobs of a step; dp: every rank is a replica running its own step
@@ -602,6 +613,9 @@ def main():
                        "text_steps": args.text_steps, "timesteps": args.timesteps, "n_layers": cfg["n_layers"],
                        "algorithmic_pflop_per_image": fl_img / 1e15,
                        "job_mfma_frac": value * fl_img / 1e12 / (world * MFMA_BF16_PEAK_TFLOPS),
+                       "vq_encode_ms": vq_ms[0] if vq_ms else None, "vq_decode_ms": vq_ms[1] if vq_ms else None,
+                       "vq_note": ("A tokenizer = restatement of diffusers.VQModel (third-party, absent offline): PARITY UNPINNED; "
+                                   "its share of the step is vq_encode_ms + vq_decode_ms per step") if vq_ms else None,
                        "hipgraph_step": bool(getattr(model, "graph_replays", 0)),
                        "hipgraph_nodes_per_step_kind": {str(k): v for k, v in getattr(model, "graph_nodes", {}).items()} or None,
                        "tp_ranks_agree": ranks_agree, "tp_collective": getattr(model, "tp_collective", None),

@@ -63,6 +63,85 @@ def synthetic_state_dict(cfg: dict, seed: int = 0, device: str = "cpu", dtype=to
     return sd
 
 
+def synthetic_state_dict_peaked(cfg: dict, delta: int, seed: int = 0, device: str = "cpu", dtype=torch.bfloat16, nfreq: int = 16,
+                                amp: float = 6.0, c0: float = 1.0, small: float = 0.6, beta: float = 5.0, lns: float = 0.25) -> Dict[str, torch.Tensor]:
+    """A PEAKED synthetic checkpoint: seeded random weights with one planted circuit, so that the sampler's decisions have
+    margins far above bf16 rounding noise and decision-level parity can be asserted (and can fail).  With the flat weights of
+    synthetic_state_dict every post-CFG arg-max is a near-tie among thousands of classes and no implementation — the
+    reference on another CPU included — reproduces a free-running trajectory.
+
+    The circuit ("copy the token `delta` positions back"):
+      * every embedding carries the same component c0 along a unit vector e0, its random content is orthogonal to e0;
+      * block 0's q_proj / k_proj read (almost) only that component, so queries and keys are the same vector at every
+        position up to the rotary rotation; the planted phases (`nfreq` highest rotary frequencies, amplitude `amp`) put the
+        score maximum at key position = query position - delta: content-independent, sharp attention;
+      * block 0's v_proj ignores e0 (values carry token content), so the block writes M·norm(wte[token at i - delta]) into
+        position i, M = attn_out · v_proj;
+      * the LM head row of token v is the unit direction M·norm(wte[v]) times `beta` and a log-normal factor (so that the
+        confidences of different positions differ), plus the usual random head.
+    Everything else — the other blocks, every MLP — is the random recipe scaled by `small`: real arithmetic on every GEMM, a
+    perturbation of the planted signal.  Masked positions (all the same MASK embedding) thus predict the token delta
+    positions to their left: distinct, position-dependent, peaked predictions.  Measured on CPU (tools/dbg/peaked_explore2.py):
+    bf16 and fp32 evaluation agree on 100 % of post-CFG image arg-maxima, text arg-maxima and first-commit sets."""
+    import math
+
+    d, H = cfg["d_model"], cfg["n_heads"]
+    hd = d // H
+    kvh = cfg.get("n_kv_heads") or H
+    sd = synthetic_state_dict(cfg, seed=seed, device=device, dtype=dtype)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + 1234)
+    e0 = torch.randn(d, generator=g, device=device)
+    e0 /= e0.norm()
+    p = "model.transformer."
+    wte = sd[p + "wte.weight"].float()
+    wte = wte - (wte @ e0)[:, None] * e0[None, :] + c0 * e0[None, :]
+    sd[p + "wte.weight"] = wte.to(dtype)
+    for i in range(cfg["n_layers"]):
+        for n in ("v_proj", "attn_out", "ff_proj", "up_proj", "ff_out"):
+            if i == 0 and n in ("v_proj", "attn_out"):
+                continue
+            k = f"{p}blocks.{i}.{n}.weight"
+            sd[k] = (sd[k].float() * small).to(dtype)
+    inv = 1.0 / (cfg.get("rope_theta", 10000.0) ** (torch.arange(0, hd, 2, dtype=torch.float64) / hd))
+    qv, kv = torch.zeros(hd, dtype=torch.float64), torch.zeros(hd, dtype=torch.float64)
+    for f in range(nfreq):   # rotary pair (f, f + hd/2), model/modeling_llada.py:402-435
+        ang = delta * inv[f].item()
+        kv[f] = amp
+        qv[f], qv[f + hd // 2] = amp * math.cos(ang), -amp * math.sin(ang)
+    qv, kv = qv.float().to(device), kv.float().to(device)
+    b0 = p + "blocks.0."
+    wq = qv.repeat(H)[:, None] * e0[None, :]
+    wk = kv.repeat(kvh)[:, None] * e0[None, :]
+    sd[b0 + "q_proj.weight"] = (wq + sd[b0 + "q_proj.weight"].float() * small).to(dtype)
+    sd[b0 + "k_proj.weight"] = (wk + sd[b0 + "k_proj.weight"].float() * small).to(dtype)
+    wv = sd[b0 + "v_proj.weight"].float()
+    sd[b0 + "v_proj.weight"] = ((wv - (wv @ e0)[:, None] * e0[None, :]) * 2.0).to(dtype)
+    sd[b0 + "attn_out.weight"] = (sd[b0 + "attn_out.weight"].float() * 2.0).to(dtype)
+    # the LM head reads the copied token: row v = beta * lognormal * unit(M · norm(wte[v])) (+ the random head)
+    an = sd[b0 + "attn_norm.weight"].float()
+    lnx = wte / wte.pow(2).mean(-1, keepdim=True).add(cfg.get("rms_norm_eps", 1e-5)).sqrt() * an[None, :]
+    wo, wv2 = sd[b0 + "attn_out.weight"].float(), sd[b0 + "v_proj.weight"].float()
+    if kvh != H:   # grouped-query attention: a kv head's values reach every query head of its group
+        wv2 = wv2.view(kvh, 1, hd, d).expand(kvh, H // kvh, hd, d).reshape(H * hd, d)
+    y = (lnx @ wv2.t()) @ wo.t()
+    y = y / y.norm(dim=-1, keepdim=True)
+    scale = torch.exp(torch.randn(y.shape[0], generator=g, device=device) * lns)
+    head = sd[p + "ff_out.weight"].float()
+    sd[p + "ff_out.weight"] = (y * (beta * scale)[:, None] * (4.0 / math.sqrt(d)) + head).to(dtype)
+    return sd
+
+
+CFG_PEAKED = dict(d_model=1024, n_heads=8, n_kv_heads=8, n_layers=4, mlp_hidden_size=2048, vocab_size=134656,
+                  embedding_size=134656, rms_norm_eps=1e-5, rope_theta=500000.0, max_sequence_length=4096)
+
+
+def peaked_delta(job: dict) -> int:
+    """The copy distance used with synthetic_state_dict_peaked for a synthetic_job: the masked output-image and text positions
+    all copy from inside the conditioning image span (distinct image codes)."""
+    return job["image_start"] - 40
+
+
 def host_isa() -> str:
     """Which bf16 GEMM code path this host's CPU gives torch / oneDNN: the reference's CPU forward (and therefore every
     float fixture recorded from it) is bit-reproducible only within one class.  Fixtures that contain float

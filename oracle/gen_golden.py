@@ -22,6 +22,9 @@ once per class, <name>.<synth.host_isa()>.npz; this script writes the file of th
                      fake tokenizer, imported with a stub `diffusers`
   sampler_noisy.npz  the same at temperature 1.0 / text_temperature 0.7 with every draw taken from a seeded CPU generator
   e2e_tiny.*.npz     generate_ti2ti with the real tiny model at temperature 0: ids at every model call + outputs
+  peaked_traj.*.npz  generate_ti2ti free-running on the PEAKED synthetic checkpoint (synth.synthetic_state_dict_peaked, 4 blocks,
+                     d = 1024) at BASELINE configs[0] geometry (L = 1654, 32 text + 16 image steps, 64 model calls): ids of every
+                     call + outputs — the trajectory a re-ordered GEMM can be held to (decision margins >> bf16 noise)
   dllm_cache.*.npz   LLaDAModelLM.forward(use_cache=True, to_compute_mask=..., cat=...) on the tiny model: a prime call and
                      compute-mask steps on changed ids, two cache keys, with and without caching(True): logit slices +
                      arg-max of the returned logit cache — model/modeling_llada.py:593-600,929-940,1244-1245,1406-1426
@@ -353,6 +356,66 @@ def compute_e2e() -> dict:
     kw = dict(text_steps=8, timesteps=4, temperature=0.0, text_temperature=0.0, cfg_scale=0.0, cfg_img=4.0)
     calls, vq, text = run_reference_sampler(fn, job, **kw)
     return dict(calls=torch.cat(calls, 0).numpy(), vq=np.array(vq, np.int64), text=np.array(text, np.int64))
+
+
+PEAKED_KW = dict(text_steps=32, timesteps=16, temperature=0.0, text_temperature=0.0, cfg_scale=0.0, cfg_img=4.0)
+
+
+def peaked_job():
+    """BASELINE configs[0] geometry: 256x256 output, 512x512 conditioning image, 256 text tokens: L = 1654."""
+    return synth.synthetic_job(256, 256, text_gen_length=256, prompt_len=64, uncond_prompt_len=24, seed=1)
+
+
+def compute_peaked() -> dict:
+    """The unmodified reference — generate_ti2ti + LLaDAForMultiModalGeneration (4 blocks, d = 1024, bf16, CPU) — free-running
+    on the PEAKED synthetic checkpoint (synth.synthetic_state_dict_peaked: decisions far above bf16 noise) at configs[0]
+    geometry and schedule: 32 text + 16 image steps, 64 model calls.  Records the ids of every model call, the outputs, and
+    per model call the smallest top-1 / top-2 margin (in logit sigmas) among the still-masked text rows (for the report)."""
+    cfg = synth.CFG_PEAKED
+    job = peaked_job()
+    model = build_reference_model(cfg, synth.synthetic_state_dict_peaked(cfg, synth.peaked_delta(job)))
+    margins = []
+
+    def fn(ids, _idx):
+        with torch.no_grad():
+            out = model(ids, infer=True, use_cache=False)
+        masked = ids[0, job["text_start"]:job["text_end"]] == synth.MASK   # the rows a text step can still commit
+        if bool(masked.any()):
+            lg = out.logits[0, job["text_start"]:job["text_end"]][masked].float()
+            top = lg.topk(2, -1).values
+            margins.append(((top[:, 0] - top[:, 1]) / lg.std(-1)).min().item())
+        else:
+            margins.append(float("inf"))
+        return out
+
+    # the confidences every re-mask cut is taken on (mask_by_random_topk's `probs` argument, bf16): torch.sort leaves the
+    # order of exact ties unspecified (oracle/generate_oracle.py: tie_order), so a comparison has to know where the ties are
+    import generators.parallel_generator as pgen
+
+    commits, real = [], pgen.mask_by_random_topk
+
+    def spy(mask_len, probs, temperature=1.0, generator=None):
+        m = real(mask_len, probs, temperature, generator)
+        commits.append((bits(probs[0]), m[0].numpy().copy(), int(mask_len.reshape(-1)[0])))
+        return m
+
+    pgen.mask_by_random_topk = spy
+    try:
+        calls, vq, text = run_reference_sampler(fn, job, **PEAKED_KW)
+    finally:
+        pgen.mask_by_random_topk = real
+    return dict(calls=torch.cat(calls, 0).numpy().astype(np.int32), vq=np.array(vq, np.int64), text=np.array(text, np.int64),
+                min_text_margin_sigma=np.array(margins, np.float32),
+                commit_conf=np.stack([c[0] for c in commits]), commit_masking=np.stack([c[1] for c in commits]),
+                commit_mask_len=np.array([c[2] for c in commits], np.int32))
+
+
+def gen_peaked():
+    d = compute_peaked()
+    np.savez_compressed(os.path.join(OUT, f"peaked_traj.{synth.host_isa()}.npz"), **d)
+    print(f"peaked_traj.{synth.host_isa()}: {d['calls'].shape[0]} model calls of L = {d['calls'].shape[1]}; "
+          f"{len(set(d['vq'].tolist()))} distinct VQ ids, {len(set(d['text'].tolist()))} distinct text ids; "
+          f"smallest top-1/top-2 text margin over all calls {d['min_text_margin_sigma'].min():.2f} sigma")
 
 
 def gen_e2e():
@@ -778,4 +841,5 @@ if __name__ == "__main__":
     gen_sampler_noisy()
     gen_forward()
     gen_e2e()
+    gen_peaked()
     gen_dllm_cache()

@@ -34,10 +34,17 @@ def generate(model_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.
              cfg_scale: float, cfg_img: float, uncon_text: Optional[torch.Tensor], uncon_image: Optional[torch.Tensor],
              text_vocab_size: int = 126356, codebook_size: int = 8192, trace: Optional[list] = None,
              image_step_list: Optional[list] = None, temperature: float = 0.0, text_temperature: float = 0.0,
-             generator=None, remasking: str = "low_confidence") -> torch.Tensor:
+             generator=None, remasking: str = "low_confidence", tie_order: str = "stable",
+             commit_trace: Optional[list] = None) -> torch.Tensor:
     """Returns the final ids before the random fill (:360-362).  temperature / text_temperature > 0 draw from
     `generator` (a CPU generator) with the reference's calls in the reference's order: torch.rand for the text Gumbel
     noise (:13-16), torch.multinomial for the image tokens (:297-302), torch.randn for the re-mask jitter (:30-33)."""
+    # tie_order: which of several EXACTLY tied bf16 confidences stay masked at the re-mask cut (:41).  The reference calls
+    # torch.sort without stable=True; on CPU that is stable for small rows (N <= 16 observed) and NOT stable beyond (PyTorch
+    # 2.10, AVX-512: 20 of 20 tie-heavy rows of N >= 64 come out in another order than the stable sort) — the order of ties
+    # is a property of the PyTorch build and CPU, not of the algorithm.  "stable" = lowest index first (the C oracle and the
+    # HIP kernel); "torch" = call torch.sort here exactly as the reference does (same host + same PyTorch = same order),
+    # which is what pins this file against a reference recording with many ties (tests/golden/peaked_traj.*.npz).
     ids = input_ids.clone()
     assert ids.shape[0] == 1
     image_end = image_start + seq_len + seq_len // newline_every
@@ -102,6 +109,21 @@ def generate(model_fn: Callable[[torch.Tensor], torch.Tensor], input_ids: torch.
                 if remasking == "random":  # keep the GLOBAL generator in step: the reference draws even at temperature 0 (A.2)
                     torch.randn((1, seq_len), dtype=torch.bfloat16)
                 noise = torch.zeros((1, seq_len), dtype=torch.bfloat16)  # temperature 0: 0 * randn
-            ids = so.image_commit(ids, pos, am, pm, noise, temperature * (1.0 - ratio), mlen, MASK_TOKEN, text_vocab_size,
-                                  codebook_size)
+            if tie_order == "torch":   # parallel_generator.py:304-344 + mask_by_random_topk :23-70 in torch ops
+                cur = ids[0, pos]
+                unknown = (cur == MASK_TOKEN)[None, :]
+                sampled = torch.where(unknown, am.long(), (cur - text_vocab_size)[None, :]).clamp(0, codebook_size - 1)
+                sel = torch.where(unknown, pm, torch.tensor(torch.finfo(torch.bfloat16).max, dtype=torch.bfloat16))
+                k = max(1, min(int(unknown.sum()) - 1, mlen))
+                conf = torch.log(sel + 1e-10) + (temperature * (1.0 - ratio)) * noise
+                order = torch.sort(conf, dim=-1, descending=False)[1]
+                masking = torch.zeros_like(sel, dtype=torch.bool)
+                masking[0, order[0, :k]] = True
+                ids = ids.clone()
+                ids[0, pos] = torch.where(masking[0], torch.tensor(MASK_TOKEN), sampled[0] + text_vocab_size)
+                if commit_trace is not None:
+                    commit_trace.append((sel.clone(), masking.clone(), k))
+            else:
+                ids = so.image_commit(ids, pos, am, pm, noise, temperature * (1.0 - ratio), mlen, MASK_TOKEN, text_vocab_size,
+                                      codebook_size)
     return ids

@@ -163,7 +163,7 @@ def test_full_depth_8b_forward_vs_oracle():
     cfg = dict(synth.CFG_8B)
     n_layers = int(os.environ.get("MMADA_PARITY_LAYERS", cfg["n_layers"]))
     cfg["n_layers"] = n_layers
-    want_tp = [int(t) for t in os.environ.get("MMADA_PARITY_TP", "2,4").split(",") if t]   # in-process rank groups
+    want_tp = [int(t) for t in os.environ.get("MMADA_PARITY_TP", "2,4,8").split(",") if t]   # in-process rank groups
     want_cfg = os.environ.get("MMADA_PARITY_CFG", "1") != "0"   # one image step's dual-CFG decisions (2 more oracle forwards)
     sd_dev = synth.synthetic_state_dict(cfg, seed=3, device=DEV)
     model = LLaDAForMultiModalGeneration.from_state_dict(synth.full_config(cfg), sd_dev, device=DEV, max_batch=2)
@@ -212,7 +212,7 @@ def test_full_depth_8b_forward_vs_oracle():
     tp_hip = {}
     os.environ.setdefault("MMADA_TP_TIMEOUT_S", "20")
     for tp in want_tp:
-        ranks, streams = tp_group(cfg, sd_dev, tp, (L + 7) // 8 * 8)
+        ranks, streams = tp_group(cfg, sd_dev, tp, (2 if want_cfg else 1) * ((L + 7) // 8 * 8))
         tp_each(ranks, streams, lambda m: m.forward_body(ids_d))
         hid = tp_each(ranks, streams, lambda m: m.hidden_state())
         tl = tp_each(ranks, streams, lambda m: m.head_rows(trow, 0, V))
@@ -222,7 +222,18 @@ def test_full_depth_8b_forward_vs_oracle():
         for r in range(1, tp):  # every rank holds the same all-gathered rows
             assert torch.equal(hid[0], hid[r]), f"TP={tp}: residual stream of rank {r} differs from rank 0"
             assert torch.equal(tl[0], tl[r]) and torch.equal(il[0], il[r]), f"TP={tp}: logits of rank {r} differ"
-        tp_hip[tp] = (hid[0].cpu(), tl[0].cpu(), il[0].cpu())
+        ul = None
+        if want_cfg:   # the unconditional pair of the image step through the SAME rank group (a batch-2 forward)
+            unc_d = unc.to(DEV)
+            tp_each(ranks, streams, lambda m: m.forward_body(unc_d))
+            irow2_tp = torch.cat([irow, irow + L])
+            ul = tp_each(ranks, streams, lambda m: m.head_rows(irow2_tp, synth.TEXT_VOCAB, synth.TEXT_VOCAB + synth.CODEBOOK))
+            for m in ranks:
+                assert m.comm_status()["error"] == 0, f"TP={tp} rank {m.tp_rank}: {m.comm_status()}"
+            for r in range(1, tp):
+                assert torch.equal(ul[0], ul[r]), f"TP={tp}: unconditional logits of rank {r} differ"
+            ul = ul[0].cpu().view(2, len(pos), -1)
+        tp_hip[tp] = (hid[0].cpu(), tl[0].cpu(), il[0].cpu(), ul)
         del ranks, streams, hid, tl, il
         torch.cuda.empty_cache()
     sd = {k: v.cpu() for k, v in sd_dev.items()}
@@ -283,7 +294,7 @@ def test_full_depth_8b_forward_vs_oracle():
     # (round-2 review: on the 2-block tiny model TP = 2 was 6x further from TP = 1 than TP = 1 from the oracle; what decides
     # whether the reduce-scatter half must carry fp32 is the distance from EXACT arithmetic after 32 blocks at d = 4096)
     tp_rep = {}
-    for tp, (hid, tl, il) in tp_hip.items():
+    for tp, (hid, tl, il, _ul) in tp_hip.items():
         row = {"stream_vs_oracle": _rel(hid, taps_ref[-1]), "stream_vs_tp1": _rel(hid, taps_hip[-1]),
                "text_logits": _logit_report(f"TP={tp} text logits", tl, text_ref, text_f32),
                "image_logits": _logit_report(f"TP={tp} image logits", il, img_ref, img_f32)}
@@ -295,6 +306,20 @@ def test_full_depth_8b_forward_vs_oracle():
         print(f"TP={tp}: residual stream after block {n_layers - 1}: vs oracle {row['stream_vs_oracle'][0]:.3e}, vs TP=1 "
               f"{row['stream_vs_tp1'][0]:.3e}" + (f", vs fp32 {row['stream_vs_fp32'][0]:.3e} (TP=1 {row['tp1_stream_vs_fp32'][0]:.3e}, "
                                                   f"reference bf16 {row['oracle_bf16_stream_vs_fp32'][0]:.3e})" if want_f32 else ""))
+    if tp_rep:
+        _save("tp_depth_8b" if n_layers == 32 else f"tp_depth_{n_layers}_8b", {"n_layers": n_layers, "L": L, "partials": "bf16", **tp_rep})
+    # TP = k differs from TP = 1 only by the bf16 rounding of k partial sums per row-parallel GEMM: its consumed logits must
+    # sit as close to TP = 1's as TP = 1's sit to the oracle's (both are one re-association of the same bf16 arithmetic)
+    tp1_img_vs_oracle = (img_hip.float() - img_ref.float()).abs().mean().item()
+    for tp, (_hid, _tl, il, ul) in tp_hip.items():
+        d_img = (il.float() - img_hip.float()).abs().mean().item()
+        tp_rep[f"tp{tp}"]["image_logits_vs_tp1_mean_abs"] = d_img
+        tp_rep[f"tp{tp}"]["tp1_image_logits_vs_oracle_mean_abs"] = tp1_img_vs_oracle
+        assert d_img <= 1.5 * tp1_img_vs_oracle, (tp, d_img, tp1_img_vs_oracle)
+        if ul is not None and unc_hip is not None:
+            d_unc = (ul.float() - unc_hip.float()).abs().mean().item()
+            tp_rep[f"tp{tp}"]["uncond_pair_logits_vs_tp1_mean_abs"] = d_unc
+            assert d_unc <= 1.5 * tp1_img_vs_oracle, (tp, d_unc, tp1_img_vs_oracle)
     if tp_rep:
         _save("tp_depth_8b" if n_layers == 32 else f"tp_depth_{n_layers}_8b", {"n_layers": n_layers, "L": L, "partials": "bf16", **tp_rep})
     for name, row in tp_rep.items():
@@ -323,8 +348,8 @@ def test_full_depth_8b_forward_vs_oracle():
             sets["fp32"] = (img_f32.view(1, Nq, -1).contiguous(), unc_f32)
             unc_env = {"hip_vs_fp32_mean_abs": (unc_hip.float() - unc_f32.float()).abs().mean().item(),
                        "oracle_bf16_vs_fp32_mean_abs": (unc_ref.float() - unc_f32.float()).abs().mean().item()}
-        for tp, (_, _, il) in tp_hip.items():
-            sets[f"hip_cond_tp{tp}"] = (il.view(1, Nq, -1).contiguous(), unc_hip)   # TP conditional branch, TP=1 uncond pair
+        for tp, (_, _, il, ul) in tp_hip.items():   # the whole image step under tensor parallelism: all three branches
+            sets[f"hip_tp{tp}"] = (il.view(1, Nq, -1).contiguous(), ul if ul is not None else unc_hip)
         res = {}
         for name, (c, u) in sets.items():
             am, pm, probs = so.image_probs(c.to(torch.bfloat16), u[0:1].contiguous().to(torch.bfloat16),
