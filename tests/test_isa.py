@@ -13,8 +13,10 @@ import isa_check  # noqa: E402
 
 
 def test_gemm8_counted_waits_see_only_lds_dma():
-    """Also: no static LDS, LDS-DMA in the scalar-base form, and (STORE / RESID / SwiGLU builds) nothing but 16-byte stores
-    in the epilogue, fed by v_permlane16_swap."""
+    """Also: no static LDS, LDS-DMA in the scalar-base form, (STORE / RESID / SwiGLU builds) nothing but 16-byte stores in the
+    epilogue, fed by v_permlane16_swap — and the literal immediate of every counted wait in a steady-state loop equals that
+    loop's own LDS-DMA count per K-tile (`four` of the schedule model in tests/test_host_logic.py::test_gemm8_schedule): an
+    edited wait_vm<> count in csrc/gemm8.hip fails HERE (checked by mutation: FOUR - 1 in one phase -> 10 errors)."""
     report, errors = isa_check.check_gemm8()
     assert len(report) == 16, report                      # 4 epilogues x 4 tile configurations
     assert not errors, "\n".join(errors)

@@ -149,6 +149,32 @@ def check_gemm8(asm=None):
             transfer(blocks[i], state[i], found)
             n_wait += sum(1 for s in blocks[i] if re.match(r"s_waitcnt vmcnt\(", s))
         errors += sorted(set(found))
+        # The steady-state loops (a back edge; the body is two K-tiles): the literal immediate of every counted wait must be
+        # this wave's LDS-DMA instructions of FOUR half-tiles = the loop's own LDS-DMA count per K-tile — the quantity
+        # `four` of the schedule model tests/test_host_logic.py::_gemm8_program simulates — and a K-tile has three (first
+        # schedule) or four (balanced) such waits.  An edit of a wait_vm<> count in csrc/gemm8.hip fails here, not only in
+        # a timing-dependent race on the GPU.
+        n_loops = 0
+        for i, outs in enumerate(succ):
+            for j in outs:
+                if j != i:
+                    continue   # the steady-state loop is one basic block branching to itself
+                loop = blocks[i]
+                dma = sum(1 for x in loop if x.startswith("global_load_lds_dwordx4"))
+                waits = [int(m.group(1)) for x in loop for m in [re.match(r"s_waitcnt vmcnt\((\d+)\)", x)] if m]
+                if dma < 8 or not waits:
+                    continue   # not a main loop (epilogue / planner loops)
+                n_loops += 1
+                if dma % 2:
+                    errors.append(f"{name}: a main loop issues {dma} LDS-DMA instructions (two K-tiles expected)")
+                    continue
+                four = dma // 2
+                if any(w != four for w in waits):
+                    errors.append(f"{name}: main-loop waits {sorted(set(waits))} != {four} (this wave's LDS-DMA of four half-tiles)")
+                if len(waits) not in (6, 8):
+                    errors.append(f"{name}: {len(waits)} counted waits in a two-K-tile loop (6 or 8 expected)")
+        if n_loops < 1:
+            errors.append(f"{name}: no steady-state loop found")
         lds = int(meta.get(name, {}).get("group_segment_fixed_size", "0"))
         if lds != 0:
             errors.append(f"{name}: static LDS of {lds} bytes (the kernel assumes its dynamic LDS segment starts at 0)")
