@@ -336,7 +336,11 @@ int mmada_profile_end(mmada_handle* h, int32_t* count_out /*[5]*/, double* ms_ou
  *   "gemm_config"    -1 automatic (default: the cost model of csrc/gemm.hip); 0..3 the 8-phase kernel's tile configuration
  *                    (320x256, 256x256, 160x256, 320x128); 1000 + BM the 16-wave kernel with that row-tile height
  *   "attention_form" -1 automatic (default: MMADA_ATTN_FORM or 1); 0 the round-2 issue order; 1 software-pipelined matrix
- *                    blocks (fragments prefetched in registers, pinned issue order) */
+ *                    blocks (fragments prefetched in registers, pinned issue order); 2 attention64 (64 query rows per wave,
+ *                    one wave per SIMD, hand-owned accumulator file)
+ *   "gemm_short_tiles" 1 (default): the 320-row configurations use a row-tile pitch of 304 when ntm - 1 tiles of 304 rows and
+ *                    one of <= 320 cover M (M = B * 2440: 5 % fewer MFMAs in all but the last row tile); 0: full height
+ *   "probe_variant"  MFMA shape / occupancy of mmada_mfma_probe (tools/probe_variants.py) */
 int mmada_set_option(const char* name, int value);
 
 /* ---- attainable-MFMA probe (bench.py's roofline.attainable_tflops; measurement only, no reference counterpart) -----

@@ -305,6 +305,7 @@ int mmada_profile_end(mmada_handle* h, int32_t* count_out, double* ms_out, doubl
 int mmada_set_option(const char* name, int value) {
     if (!name) return mm_fail("mmada_set_option: null name");
     if (!strcmp(name, "gemm_config")) { gemm_force_config(value); return 0; }
+    if (!strcmp(name, "gemm_short_tiles")) { gemm8_set_short_tiles(value); return 0; }
     if (!strcmp(name, "attention_form")) { attention_force_form(value); return 0; }
     if (!strcmp(name, "probe_variant")) { mfma_probe_set_variant(value); return 0; }
     return mm_fail("mmada_set_option: unknown option '%s'", name);

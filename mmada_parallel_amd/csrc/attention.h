@@ -57,6 +57,18 @@ MM_DEVICE lptr_t lds_at(int byte_off) { return (lptr_t)(uint32_t)byte_off; }
 
 #define A8_SB() __builtin_amdgcn_sched_barrier(0)
 
+// One 16-byte-per-lane LDS-DMA request as an asm statement.  With the BUILTIN (__builtin_amdgcn_global_load_lds) hipcc places
+// `s_waitcnt lgkmcnt(0)` in front of the next asm statement that reads a register an LDS read is still writing — it gives up
+// counting once an LDS-writing VMEM operation is in flight next to an asm it cannot see into (tools/dbg/wc reproduces that in
+// 20 lines) — so every K / vT fragment wait in the tile loop drained the whole read queue: 24 % of the wave's cycles parked
+// (SQ_WAIT_ANY, profiles/r04_pmc_sq_attention_forms.txt).  A request the compiler does not know leaves its own, COUNTED
+// lgkmcnt(N) waits in place.  The tile barrier's explicit `s_waitcnt vmcnt(0)` is what orders the DMA, as before; the
+// "memory" clobber keeps the compiler's LDS reads on their side of the statement.
+MM_DEVICE void dma16(const char* sbase, unsigned voff, int lds_byte) {
+    const int m0v = __builtin_amdgcn_readfirstlane(lds_byte);
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(m0v) : "m0", "memory");
+}
+
 }  // namespace attn_detail
 
 // attention64.hip

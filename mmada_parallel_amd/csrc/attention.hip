@@ -249,15 +249,11 @@ __global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
         const char* vb = (const char*)Vp + (size_t)kt * KB * 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            unsigned off = koff[i];
-            asm volatile("" : "+s"(kb), "+v"(off));
-            __builtin_amdgcn_global_load_lds((gptr_t)(kb + off), lds_at(BUF * 2 * TILE_BYTES + wave * 4096 + i * 1024), 16, 0, 0);
+            dma16(kb, koff[i], BUF * 2 * TILE_BYTES + wave * 4096 + i * 1024);   // asm form: attention.h
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            unsigned off = voff[i];
-            asm volatile("" : "+s"(vb), "+v"(off));
-            __builtin_amdgcn_global_load_lds((gptr_t)(vb + off), lds_at(BUF * 2 * TILE_BYTES + TILE_BYTES + wave * 4096 + i * 1024), 16, 0, 0);
+            dma16(vb, voff[i], BUF * 2 * TILE_BYTES + TILE_BYTES + wave * 4096 + i * 1024);
         }
     };
     int kro[8], vro[4];

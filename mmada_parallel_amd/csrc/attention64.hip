@@ -217,15 +217,13 @@ MM_DEVICE void attn64_body(const AttnArgs& a, int bid, int per_pair, int qb_firs
         constexpr int SLOT = decltype(slot_)::value, I = decltype(i_)::value;
         const char* kb = (const char*)Kp + (size_t)min(kt, nkt - 1) * KB * 256 + (size_t)(wave * 16 + I * 4) * 256;
         unsigned off = klane ^ (unsigned)(I << 6);
-        asm volatile("" : "+s"(kb), "+v"(off));
-        __builtin_amdgcn_global_load_lds((gptr_t)(kb + off), lds_at(KBASE0 + SLOT * TILE_BYTES + wave * 4096 + I * 1024), 16, 0, 0);
+        dma16(kb, off, KBASE0 + SLOT * TILE_BYTES + wave * 4096 + I * 1024);
     };
     auto dma_v = [&](auto slot_, auto i_, int kt) {
         constexpr int SLOT = decltype(slot_)::value, I = decltype(i_)::value;
         const char* vb = (const char*)Vp + (size_t)min(kt, nkt - 1) * KB * 2 + (size_t)(wave * 32 + I * 8) * a.Lkv * 2;
         unsigned off = vlane ^ (unsigned)((I & 1) << 6);
-        asm volatile("" : "+s"(vb), "+v"(off));
-        __builtin_amdgcn_global_load_lds((gptr_t)(vb + off), lds_at(VBASE0 + SLOT * TILE_BYTES + wave * 4096 + I * 1024), 16, 0, 0);
+        dma16(vb, off, VBASE0 + SLOT * TILE_BYTES + wave * 4096 + I * 1024);
     };
     int kro[8], vro[4];
     {

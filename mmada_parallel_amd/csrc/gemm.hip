@@ -149,7 +149,7 @@ __global__ __launch_bounds__(NTHREADS, 4) void gemm_bt_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < T::FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     mainloop<BM, WM, WN>(g, smem, mt * BM, nt * BN, 0, g.K / BK, acc, wave, lane);
-    gemm_epilogue<EPI, T::TM, T::TN, WN>(g, mt * BM, nt * BN, acc, wave, lane);
+    gemm_epilogue<EPI, T::TM, T::TN, WN>(g, mt * BM, nt * BN, acc, wave, lane, g.M);
     gemm_publish(g, wave);
 }
 

@@ -85,6 +85,15 @@ struct Gemm8 {
     static constexpr int REM = RA0 ? RA0 : RA1;           // the one wave-uniform predicate that separates the two code paths
     static constexpr int NB = NPB / 8;
     static_assert(WM * WN == 8 && TM % 16 == 0 && TN % 32 == 0 && FA1 >= 1, "wave tile");
+    // SHORT ROW TILES (round 4).  The stream has M = B * 2440 rows: 152.5 / 305 fragments of 16 rows, which 320-row tiles
+    // cover with 160 / 320 — 4.7 % of every MFMA cluster multiplies rows that do not exist.  305 = 15 * 19 + 20 and
+    // 153 = 7 * 19 + 20: with a row-tile pitch of 304 every row tile but the last one is 19 fragments high, the last one
+    // takes what is left (<= 320).  A short tile is the same tile whose LAST wave row leaves out its last A fragment
+    // (DROP = 1: FA1 - 1 fragments in the second A half): waves 4-7 issue 16 instead of 20 MFMAs in P3 and P4, a SIMD 152
+    // instead of 160 per K-tile.  Nothing else moves: same LDS image (the 16 rows are staged and not read), same barriers,
+    // same k order for every output that is computed — the same bits — and the epilogue stops at the tile's last row.
+    static constexpr bool CAN_DROP = WM == 2 && FA1 >= 2 && BM == 320;
+    static constexpr int SHORT_BM = BM - 16;
     static_assert(NPB % 8 == 0 && (RA0 == 0 || RA1 == 0 || RA0 == RA1) && NPA0 <= 24 && NPA1 <= 24, "piece split");
     static_assert(LDS <= 160 * 1024, "LDS");
 
@@ -181,11 +190,11 @@ struct Gemm8 {
             __builtin_amdgcn_global_load_lds((gptr_t)(src + wlane), lds_at(B * B_BYTES + wlds[H][i]), 16, 0, 0);
         }
     }
-    template <int B, int H>
+    template <int B, int H, int DROP = 0>
     MM_DEVICE void read_a() {
         if (OPT & 16) return;
 #pragma unroll
-        for (int mi = 0; mi < (H ? FA1 : FA0); ++mi)
+        for (int mi = 0; mi < (H ? FA1 - DROP : FA0); ++mi)
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) af[mi][kk] = *lds_frag(ra[kk] + B * A_BYTES + ((H ? FA0 * 16 : 0) + mi * 16) * 128);
     }
@@ -197,12 +206,12 @@ struct Gemm8 {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) bf[nj][kk] = *lds_frag(rb[kk] + B * B_BYTES + (H * FB * 16 + nj * 16) * 128);
     }
-    template <int H, int NH, bool SWAP>
+    template <int H, int NH, bool SWAP, int DROP = 0>
     MM_DEVICE void mma(bf16x8 (&bf)[FB][2]) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int mi = 0; mi < (H ? FA1 : FA0); ++mi)
+            for (int mi = 0; mi < (H ? FA1 - DROP : FA0); ++mi)
 #pragma unroll
                 for (int nj = 0; nj < FB; ++nj) {
                     f32x4& c = acc[(H ? FA0 : 0) + mi][NH * FB + nj];
@@ -215,7 +224,7 @@ struct Gemm8 {
 
     // One K-tile (index kt, LDS buffer B).  TAIL 0: steady state (kt + 2 < nk); 1: second-to-last; 2: last K-tile.
     // LDS-DMA queue, oldest first, at the top of P1(kt): B1(kt) A1(kt) A0(kt+1) B0(kt+1)  (A0, B0 of kt have landed).
-    template <int B, int NA0, int NA1, int TAIL, bool SWAP>
+    template <int B, int NA0, int NA1, int TAIL, bool SWAP, int DROP>
     MM_DEVICE void tile(int kt) {
         constexpr int FOUR = NA0 + NA1 + 2 * NB;  // this wave's LDS-DMA instructions of four half-tiles
         // ---- P1: quadrant (A0, B0) ----
@@ -235,16 +244,16 @@ struct Gemm8 {
         G8_BARRIER();
         // ---- P3: (A1, B1) ----
         if (TAIL == 0) stage_a<B, 0, NA0>(kt + 2);
-        read_a<B, 1>();
+        read_a<B, 1, DROP>();
         G8_BARRIER();
-        mma<1, 1, SWAP>(bf1);
+        mma<1, 1, SWAP, DROP>(bf1);
         G8_BARRIER();
         // ---- P4: (A1, B0) ----
         if (TAIL == 0) stage_w<B, 0>(kt + 2);
         if (TAIL == 0) wait_vm<FOUR>();                      // A0, B0 of K-tile kt+1 have landed
         else if (TAIL == 1) wait_vm<NB + NA1>();
         G8_BARRIER();
-        mma<1, 0, SWAP>(bf0);
+        mma<1, 0, SWAP, DROP>(bf0);
         G8_BARRIER();
     }
 
@@ -254,7 +263,7 @@ struct Gemm8 {
     // already in registers: it was read during P4 of the previous K-tile, into the W register set that P3 had just
     // released — the two sets swap roles from one K-tile to the next, which is the buffer parity B).  Every phase stages
     // one half-tile, reads one half-tile and retires one half-tile; four half-tiles stay in flight behind every wait.
-    template <int B, int NA0, int NA1, int TAIL, bool SWAP>
+    template <int B, int NA0, int NA1, int TAIL, bool SWAP, int DROP>
     MM_DEVICE void tile_bal(int kt) {
         constexpr int FOUR = NA0 + NA1 + 2 * NB;  // this wave's LDS-DMA instructions of four half-tiles
         bf16x8(&F)[FB][2] = B ? bf1 : bf0;        // holds W half 0 of this K-tile
@@ -275,11 +284,11 @@ struct Gemm8 {
         G8_BARRIER();
         // ---- P3: (A1, B1) ----
         if (TAIL == 0) stage_w<B, 0>(kt + 2);
-        read_a<B, 1>();
+        read_a<B, 1, DROP>();
         if (TAIL == 0) wait_vm<FOUR>();                      // B0(kt+1) has landed
         else if (TAIL == 1) wait_vm<NA0 + NB + NA1>();
         G8_BARRIER();
-        mma<1, 1, SWAP>(S);
+        mma<1, 1, SWAP, DROP>(S);
         G8_BARRIER();
         // ---- P4: (A1, B0) ----
         if (TAIL == 0) stage_a<B, 0, NA0>(kt + 2);
@@ -287,11 +296,11 @@ struct Gemm8 {
         if (TAIL == 0) wait_vm<FOUR>();                      // A0(kt+1) has landed
         else if (TAIL == 1) wait_vm<NB + NA1>();
         G8_BARRIER();
-        mma<1, 0, SWAP>(F);
+        mma<1, 0, SWAP, DROP>(F);
         G8_BARRIER();
     }
 
-    template <int NA0, int NA1, bool SWAP>
+    template <int NA0, int NA1, bool SWAP, int DROP>
     MM_DEVICE void run(int nk, int grp) {
         constexpr bool BAL = (OPT & 2) != 0;
         // the vector-memory queue is empty here at run time; saying so keeps the static check of the counted waits
@@ -307,22 +316,32 @@ struct Gemm8 {
         if ((OPT & 1) && grp == 1) __builtin_amdgcn_s_setprio(1);
         if constexpr (BAL) {
             for (int kt = 0; kt + 2 < nk; kt += 2) {
-                tile_bal<0, NA0, NA1, 0, SWAP>(kt);
-                tile_bal<1, NA0, NA1, 0, SWAP>(kt + 1);
+                tile_bal<0, NA0, NA1, 0, SWAP, DROP>(kt);
+                tile_bal<1, NA0, NA1, 0, SWAP, DROP>(kt + 1);
             }
-            tile_bal<0, NA0, NA1, 1, SWAP>(nk - 2);
-            tile_bal<1, NA0, NA1, 2, SWAP>(nk - 1);
+            tile_bal<0, NA0, NA1, 1, SWAP, DROP>(nk - 2);
+            tile_bal<1, NA0, NA1, 2, SWAP, DROP>(nk - 1);
         } else {
             for (int kt = 0; kt + 2 < nk; kt += 2) {
-                tile<0, NA0, NA1, 0, SWAP>(kt);
-                tile<1, NA0, NA1, 0, SWAP>(kt + 1);
+                tile<0, NA0, NA1, 0, SWAP, DROP>(kt);
+                tile<1, NA0, NA1, 0, SWAP, DROP>(kt + 1);
             }
-            tile<0, NA0, NA1, 1, SWAP>(nk - 2);
-            tile<1, NA0, NA1, 2, SWAP>(nk - 1);
+            tile<0, NA0, NA1, 1, SWAP, DROP>(nk - 2);
+            tile<1, NA0, NA1, 2, SWAP, DROP>(nk - 1);
         }
         if (grp == 0) G8_BARRIER();
     }
 };
+
+// mmada_set_option("gemm_short_tiles", 0) / MMADA_GEMM_SHORT_TILES=0: every row tile full height (the round-3 kernel; A/B timing)
+int g_short_tiles = -1;
+bool short_tiles_on() {
+    if (g_short_tiles < 0) {
+        const char* e = getenv("MMADA_GEMM_SHORT_TILES");
+        g_short_tiles = e && e[0] == '0' ? 0 : 1;
+    }
+    return g_short_tiles != 0;
+}
 
 template <int EPI, class G>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
@@ -330,7 +349,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     const int ntm = (g.M + G::BM - 1) / G::BM, ntn = (g.N + G::BN - 1) / G::BN;
     int mt, nt;
     tile_coords<1024 / G::BN>(xcd_remap(blockIdx.x, gridDim.x), ntm, ntn, mt, nt);
-    const int m0 = mt * G::BM, n0 = nt * G::BN;
+    // short row tiles (Gemm8::CAN_DROP): pitch 304, every row tile but the last one ends 16 rows early
+    const bool short_tiles = G::CAN_DROP && g.row_drop != 0;
+    const bool short_tile = short_tiles && mt < ntm - 1;
+    const int m0 = mt * (short_tiles ? G::SHORT_BM : G::BM), n0 = nt * G::BN;
+    const int m_lim = short_tile ? m0 + G::SHORT_BM : g.M;   // the epilogue's view: rows of this tile only
+    const bool drop = short_tile && wave / G::WN == G::WM - 1;
     G k;
     k.init(g, m0, n0, wave, threadIdx.x & 63);
     const int nk = g.K / BK;
@@ -340,12 +364,19 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     const bool extra = G::REM != 0 && wave < G::REM;
     const bool swap = G::SW == 1 || (G::SW == 2 && !qkv_wave_is_v(g, n0 + (wave % G::WN) * G::TN));
     constexpr int NA0 = G::NPA0 / 8, NA1 = G::NPA1 / 8, XA0 = NA0 + (G::RA0 ? 1 : 0), XA1 = NA1 + (G::RA1 ? 1 : 0);
+#define G8_PATH1(A0, A1, SWP, DRP)                                                                  \
+    do {                                                                                            \
+        k.template run<A0, A1, SWP, DRP>(nk, wave >> 2);                                            \
+        const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));        \
+        if (SWP) gemm_epilogue_t<EPI, G::TM, G::TN, G::WN>(g, m0, n0, k.acc, wave, lane, m_lim);         \
+        else gemm_epilogue<EPI, G::TM, G::TN, G::WN>(g, m0, n0, k.acc, wave, lane, m_lim);               \
+    } while (0)
 #define G8_PATH(A0, A1, SWP)                                                                        \
     do {                                                                                            \
-        k.template run<A0, A1, SWP>(nk, wave >> 2);                                                 \
-        const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));        \
-        if (SWP) gemm_epilogue_t<EPI, G::TM, G::TN, G::WN>(g, m0, n0, k.acc, wave, lane);           \
-        else gemm_epilogue<EPI, G::TM, G::TN, G::WN>(g, m0, n0, k.acc, wave, lane);                 \
+        if constexpr (G::CAN_DROP) {                                                                \
+            if (drop) G8_PATH1(A0, A1, SWP, 1);                                                     \
+            else G8_PATH1(A0, A1, SWP, 0);                                                          \
+        } else G8_PATH1(A0, A1, SWP, 0);                                                            \
     } while (0)
     if (G::SW != 0 && swap) {
         if (extra) G8_PATH(XA0, XA1, true);
@@ -355,6 +386,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
         else G8_PATH(NA0, NA1, false);
     }
 #undef G8_PATH
+#undef G8_PATH1
     gemm_publish(g, wave);
 }
 
@@ -364,7 +396,11 @@ int launch_cfg8(const GemmArgs& g, hipStream_t s) {
     static MmOncePerDevice attr_set;
     MM_ONCE_PER_DEVICE(attr_set, MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)));
     const int ntm = (g.M + G::BM - 1) / G::BM, ntn = (g.N + G::BN - 1) / G::BN;
-    hipLaunchKernelGGL(fn, dim3(ntm * ntn), dim3(512), G::LDS, s, g);
+    GemmArgs ga = g;
+    // short row tiles when ntm - 1 tiles of 304 rows and one of <= 320 cover M (same tile count, 5 % fewer MFMAs in all
+    // but the last row tile): M = 2440 -> 7 x 304 + 312, M = 4880 -> 15 x 304 + 320
+    ga.row_drop = G::CAN_DROP && short_tiles_on() && ntm >= 2 && (ntm - 1) * G::SHORT_BM + G::BM >= g.M ? 1 : 0;
+    hipLaunchKernelGGL(fn, dim3(ntm * ntn), dim3(512), G::LDS, s, ga);
     MM_CHECK_HIP(hipGetLastError());
     return 0;
 }
@@ -406,6 +442,8 @@ bool gemm8_supports(const GemmArgs& g) {
            (long long)g.lda * 2 * 328 < (1ll << 31) && (long long)g.ldw * 2 * 264 < (1ll << 31) &&
            g.ldc % 8 == 0 && (g.resid == nullptr || g.ldr % 8 == 0) && ((uintptr_t)g.C & 15) == 0 && ((uintptr_t)g.resid & 15) == 0;
 }
+
+void gemm8_set_short_tiles(int on) { g_short_tiles = on != 0 ? 1 : 0; }
 
 int launch_gemm8(int epi, int cfg, const GemmArgs& g, hipStream_t s) {
     if (!gemm8_supports(g)) return mm_fail("gemm8: unsupported shape M=%d N=%d K=%d", g.M, g.N, g.K);

@@ -39,10 +39,11 @@ MM_DEVICE void tile_coords(int t, int ntm, int ntn, int& mt, int& nt) {
     nt = grp * GN + (rem - mt * gn);
 }
 
+// m_lim: first row this tile does NOT write (g.M, or the end of a short row tile of gemm8.hip).
 // Wave grid WM x WN over the block tile, a wave owns TM x TN outputs = FM x FN fragments of 16 x 16:
 //     acc[mi][ni][r] = D[m][n],  m = m0 + wm*TM + mi*16 + (lane>>4)*4 + r,  n = n0 + wn*TN + ni*16 + (lane&15)
 template <int EPI, int TM, int TN, int WN>
-MM_DEVICE void gemm_epilogue(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[TM / 16][TN / 16], int wave, int lane) {
+MM_DEVICE void gemm_epilogue(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[TM / 16][TN / 16], int wave, int lane, int m_lim) {
     constexpr int FM = TM / 16, FN = TN / 16;
     static_assert(TN % 32 == 0, "fused epilogues pair adjacent 16-column fragments");
     const int wm = wave / WN, wn = wave % WN;
@@ -57,7 +58,7 @@ MM_DEVICE void gemm_epilogue(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[TM 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int m = mrow0 + mi * 16 + r;
-                if (m >= g.M) continue;
+                if (m >= m_lim) continue;
                 // wave-uniform: the 16 rows of a fragment share one residual owner
                 const bool add = EPI == EPI_RESID && (g.resid_mod == 1 || ((m >> 4) % g.resid_mod) == g.resid_rank);
                 size_t rrow = (size_t)m;  // residual row (compact -> full layout when a row window is active)
@@ -86,7 +87,7 @@ MM_DEVICE void gemm_epilogue(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[TM 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mrow0 + mi * 16 + r;
-                    if (m >= g.M) continue;
+                    if (m >= m_lim) continue;
 #pragma unroll
                     for (int q2 = 0; q2 < FN / 2; ++q2) {
                         if (wcol0 + q2 * 32 >= g.N) continue;
@@ -108,7 +109,7 @@ MM_DEVICE void gemm_epilogue(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[TM 
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mrow0 + mi * 16 + r;
-                    if (m >= g.M) continue;
+                    if (m >= m_lim) continue;
                     const int mg = m + g.m_base;  // row of the whole [B*Lp] stream
                     const int b = mg / g.Lp;
                     int l = mg - b * g.Lp;        // rotary position
@@ -142,13 +143,13 @@ MM_DEVICE void gemm_epilogue(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[TM 
 #pragma unroll
             for (int mi = 0; mi < FM; ++mi) {
                 const int mb = mrow0 + mi * 16;  // multiple of 4; Lp is a multiple of 8 -> 4 rows share a batch
-                if (mb >= g.M) continue;
+                if (mb >= m_lim) continue;
                 const int mbg = mb + g.m_base;  // m_base is a multiple of 8: the 4 rows still share a batch element
                 const int b = mbg / g.Lp, l0 = mbg - b * g.Lp;
                 if (g.pos_map) {  // scattered rows: one 2-byte store per (row, d); only the computed rows of a cache step
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        if (mb + r >= g.M) continue;
+                        if (mb + r >= m_lim) continue;
                         const int pos = g.pos_map[mbg + r];
                         if (pos < 0) continue;
                         const size_t kp = (size_t)vt_key_pos(pos & ~3) + (pos & 3);
@@ -201,7 +202,7 @@ MM_DEVICE void swap_halves16(uint32_t& a, uint32_t& b) {
 MM_DEVICE int run8_col(int lq) { return (lq & 1) * 16 + (lq >> 1) * 8; }
 
 template <int EPI, int TM, int TN, int WN>
-MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[TM / 16][TN / 16], int wave, int lane) {
+MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[TM / 16][TN / 16], int wave, int lane, int m_lim) {
     constexpr int FM = TM / 16, FN = TN / 16;
     static_assert(TN % 32 == 0, "fused epilogues pair adjacent 16-column fragments");
     const int wm = wave / WN, wn = wave % WN;
@@ -213,7 +214,7 @@ MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[T
 #pragma unroll
         for (int mi = 0; mi < FM; ++mi) {
             const int m = mrow0 + mi * 16;
-            const bool live = m < g.M;  // the swaps below are wave-wide: every lane takes part, dead rows only skip memory
+            const bool live = m < m_lim;  // the swaps below are wave-wide: every lane takes part, dead rows only skip memory
             // wave-uniform: the 16 rows of a fragment share one residual owner
             const bool add = EPI == EPI_RESID && (g.resid_mod == 1 || ((m >> 4) % g.resid_mod) == g.resid_rank);
             size_t rrow = (size_t)m;  // residual row (compact -> full layout when a row window is active)
@@ -251,7 +252,7 @@ MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[T
 #pragma unroll
         for (int mi = 0; mi < FM; ++mi) {
             const int m = mrow0 + mi * 16;
-            const bool live = m < g.M;
+            const bool live = m < m_lim;
 #pragma unroll
             for (int q2 = 0; q2 < FN / 2; q2 += 2) {
                 uint32_t pk[2][2];
@@ -280,8 +281,8 @@ MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[T
 #pragma unroll
         for (int mi = 0; mi < FM; ++mi) {
             const int m = mrow0 + mi * 16;
-            bool live = m < g.M;
-            const int mg = min(m, g.M - 1) + g.m_base;  // row of the whole [B*Lp] stream (dead lanes: any valid row)
+            bool live = m < m_lim;
+            const int mg = min(m, m_lim - 1) + g.m_base;  // row of the whole [B*Lp] stream (dead lanes: any valid row)
             const int b = mg / g.Lp;
             int l = mg - b * g.Lp;        // rotary position
             int lr = l, lstride = g.Lkv;  // destination row / rows per head
@@ -344,3 +345,5 @@ int launch_gemm8(int epi, int cfg, const GemmArgs& g, hipStream_t s);
 // Measurement hook (tools/gemm_sweep.py, tests): force one configuration for every following launch of this process.
 //   -1: automatic (default);  0..3: GEMM8_* configuration;  1000 + BM: the 16-wave kernel with that row-tile height.
 void gemm_force_config(int code);
+// short row tiles of the 320-row configurations (gemm8.hip) on / off; on by default
+void gemm8_set_short_tiles(int on);

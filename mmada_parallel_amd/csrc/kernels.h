@@ -40,6 +40,7 @@ struct GemmArgs {
     // q_mask quirk with caching() off, :714-716,416-428).
     const int32_t* pos_map;
     int Lq, q_pos_shift;
+    int row_drop;      // set by gemm8's launcher only: row tiles of pitch BM - 16 (gemm8.hip, "short row tiles")
 };
 
 int launch_gemm(int epi, const GemmArgs& g, hipStream_t s);

@@ -100,11 +100,13 @@ def test_rmsnorm(rows, d):
 
 
 # ------------------------------------------------------------------------------------------------- GEMM configurations
-@pytest.mark.parametrize("M,N,K", [(2440, 1536, 512), (648, 1024, 1024), (8, 256, 256), (4880, 512, 4096), (328, 8200, 256)])
+@pytest.mark.parametrize("M,N,K", [(2440, 1536, 512), (648, 1024, 1024), (8, 256, 256), (4880, 512, 4096), (328, 8200, 256),
+                                   (624, 512, 256), (632, 512, 256), (5000, 256, 256)])
 def test_gemm_configurations_are_bit_identical(M, N, K):
     """Every tile configuration of both GEMM kernels (8-phase: 320x256, 256x256, 160x256, 320x128 with swapped MFMA operand
     roles and 16-byte epilogue accesses, both read schedules; 16-wave: BM 128..320) accumulates a K-tile at a time in the same order with the same
-    MFMA: the planner's choice never changes a bit of the result.  Ragged last tiles in M and N included."""
+    MFMA: the planner's choice never changes a bit of the result.  Ragged last tiles in M and N included; M = 2440, 4880, 648,
+    328, 624 take the short row tiles of the 320-row configuration (pitch 304), M = 632 and 5000 do not fit them."""
     lib = abi.lib()
     g = torch.Generator().manual_seed(M + N + K)
     A = torch.randn(M, K, generator=g).to(torch.bfloat16).to(DEV)
@@ -117,8 +119,16 @@ def test_gemm_configurations_are_bit_identical(M, N, K):
             abi.check(lib.mmada_gemm_bt(A.data_ptr(), W.data_ptr(), Cc.data_ptr(), M, N, K, st()), "gemm")
             torch.cuda.synchronize()
             outs[code] = Cc
+        # the 320-row configuration once more with every row tile at full height (short row tiles off: gemm8.hip)
+        abi.check(lib.mmada_set_option(b"gemm_config", 0), "set_option")
+        abi.check(lib.mmada_set_option(b"gemm_short_tiles", 0), "set_option")
+        Cc = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        abi.check(lib.mmada_gemm_bt(A.data_ptr(), W.data_ptr(), Cc.data_ptr(), M, N, K, st()), "gemm")
+        torch.cuda.synchronize()
+        outs["0, full-height row tiles"] = Cc
     finally:
         lib.mmada_set_option(b"gemm_config", -1)
+        lib.mmada_set_option(b"gemm_short_tiles", 1)
     ref = (A.float() @ W.float().t())
     assert ((outs[-1].float() - ref).abs() <= 2.0 ** -7 * ref.abs() + 1e-2).all()
     for code, Cc in outs.items():

@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--iters", type=int, default=25)
     ap.add_argument("--rounds", type=int, default=14)
     ap.add_argument("--warm", type=int, default=3000)
+    ap.add_argument("--data", default="randn", help="randn (the measurement), or zeros: the same instruction stream with no operand toggling — "
+                    "a launch that gets faster on zeros was held back by the power governor, not by its schedule (DIAGNOSTIC)")
     ap.add_argument("--forms", default="0,1", help="attention forms to interleave; forms > 1 exist in the -DMMADA_TUNE build only "
                     "(11: no soft-max, 12: no MFMA, 13: no tile barrier — DIAGNOSTIC, wrong results; 14: static priority)")
     args = ap.parse_args()
@@ -51,6 +53,8 @@ def main():
     abi.check(lib.mmada_set_workspace(h, (ws.data_ptr() + 255) // 256 * 256, nb), "ws")
     g = torch.Generator(device="cuda").manual_seed(0)
     q, k, v = (torch.randn(B, H, L, 128, device="cuda", generator=g).to(torch.bfloat16) for _ in range(3))
+    if args.data == "zeros":
+        q, k, v = (torch.zeros_like(t) for t in (q, k, v))
     st = torch.cuda.current_stream().cuda_stream
     flops = 4.0 * B * H * L * L * 128
     out = torch.empty(B, L, H * 128, dtype=torch.bfloat16, device="cuda")
