@@ -57,6 +57,15 @@ MM_DEVICE lds_frag_ptr lds_frag(int byte_off) { return (lds_frag_ptr)(uint32_t)b
 MM_DEVICE lptr_t lds_at(int byte_off) { return (lptr_t)(uint32_t)byte_off; }
 #pragma clang diagnostic pop
 
+// LDS-DMA as an asm statement (round 4): behind the BUILTIN hipcc stops counting LDS reads — every wait in front of an MFMA
+// cluster was lgkmcnt(0), the whole operand half had to land before the first MFMA (tools/dbg/wc reproduces it); behind a
+// request it cannot see it keeps its counted lgkmcnt(N) and the cluster starts on the first fragments.  Nothing else
+// changes: the vector-memory queue is ordered by the explicit counted waits of wait_vm, as before.
+MM_DEVICE void dma16(const char* sbase, unsigned& voff, int lds_byte) {
+    const int m0v = __builtin_amdgcn_readfirstlane(lds_byte);
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(m0v) : "m0", "memory");
+}
+
 template <int N>
 MM_DEVICE void wait_vm() {
     G8_SB();
@@ -176,8 +185,7 @@ struct Gemm8 {
             const char* src = (azero[H][i] ? Zb : Ab + arow[H][i]) + (size_t)kt * (BK * 2);
             // scalar base + 32-bit lane offset, zero-extended HERE: saddr form.  The lane offset is made opaque IN PLACE
             // (no copy: the 320-row tile has no register to spare for one).
-            asm volatile("" : "+s"(src), "+v"(alane));
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + alane), lds_at(B * A_BYTES + alds[H][i]), 16, 0, 0);
+            dma16(src, alane, B * A_BYTES + alds[H][i]);
         }
     }
     template <int B, int H>
@@ -186,8 +194,7 @@ struct Gemm8 {
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const char* src = Wb + wrow[H][i] + (size_t)kt * (BK * 2);
-            asm volatile("" : "+s"(src), "+v"(wlane));
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + wlane), lds_at(B * B_BYTES + wlds[H][i]), 16, 0, 0);
+            dma16(src, wlane, B * B_BYTES + wlds[H][i]);
         }
     }
     template <int B, int H, int DROP = 0>
