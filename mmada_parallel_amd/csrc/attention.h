@@ -63,10 +63,11 @@ MM_DEVICE lptr_t lds_at(int byte_off) { return (lptr_t)(uint32_t)byte_off; }
 // 20 lines) — so every K / vT fragment wait in the tile loop drained the whole read queue: 24 % of the wave's cycles parked
 // (SQ_WAIT_ANY, profiles/r04_pmc_sq_attention_forms.txt).  A request the compiler does not know leaves its own, COUNTED
 // lgkmcnt(N) waits in place.  The tile barrier's explicit `s_waitcnt vmcnt(0)` is what orders the DMA, as before; the
-// "memory" clobber keeps the compiler's LDS reads on their side of the statement.
+// "memory" clobber keeps the compiler's LDS reads on their side of the statement.  M0: hipcc reserves it and ignores it in a
+// clobber list; nothing else in these kernels reads it (tools/isa_check.py: check_m0, on the compiled code).
 MM_DEVICE void dma16(const char* sbase, unsigned voff, int lds_byte) {
     const int m0v = __builtin_amdgcn_readfirstlane(lds_byte);
-    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(m0v) : "m0", "memory");
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(m0v) : "memory");
 }
 
 }  // namespace attn_detail

@@ -63,7 +63,7 @@ MM_DEVICE lptr_t lds_at(int byte_off) { return (lptr_t)(uint32_t)byte_off; }
 // changes: the vector-memory queue is ordered by the explicit counted waits of wait_vm, as before.
 MM_DEVICE void dma16(const char* sbase, unsigned& voff, int lds_byte) {
     const int m0v = __builtin_amdgcn_readfirstlane(lds_byte);
-    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(m0v) : "m0", "memory");
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %1, %0" ::"s"(sbase), "v"(voff), "s"(m0v) : "memory");
 }
 
 template <int N>

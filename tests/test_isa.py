@@ -48,6 +48,11 @@ def test_attention64_owns_its_accumulator_file():
     meta, problems, k = attn64_audit.audit(s)
     assert not problems, problems
     assert not attn64_audit.mfma_operand_hazards(k)
+    import isa_check
+    assert not isa_check.check_m0("attn64_fwd_kernel", k.split("\n"))   # the asm LDS-DMA statements own M0
+    import re
+    counted = len(re.findall(r"s_waitcnt lgkmcnt\([1-9]\d*\)", k))
+    assert counted >= 60, f"{counted} counted LDS waits: the compiler drains the queue in front of the asm MFMAs again"
     assert meta["vgpr_spill_count"] == 0 and meta["private_segment_fixed_size"] == 0
     hot = [g for g in attn64_audit.gaps(k) if g[0] == 64 and g[1] < 3000]
     assert len(hot) >= 2, "the two steady-state key tiles (64 MFMAs each) of a full pass"

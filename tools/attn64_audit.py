@@ -162,6 +162,9 @@ if __name__ == "__main__":
             top = sorted(kinds.items(), key=lambda x: -x[1])[:14]
             print(f"region: {n_mfma} MFMAs, {n} instructions, fillers/gap max {max(g)} mean {sum(g) / len(g):.1f}: {g}")
             print("   ", top)
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from isa_check import check_m0
+    problems += check_m0("attn64_fwd_kernel", k.split("\n"))
     hz = mfma_operand_hazards(k)
     if hz:
         problems.append(f"{len(hz)} MFMA operand hazards, e.g. {hz[0]}")

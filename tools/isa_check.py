@@ -69,6 +69,28 @@ def kernels(asm):
     return body, meta
 
 
+def check_m0(name, lines):
+    """The LDS-DMA requests of the 8-phase GEMM and of the attention kernels are asm statements that set M0 (the LDS
+    destination) themselves.  hipcc treats m0 as a reserved register and ignores it in a clobber list, so the contract is
+    checked on the compiled code: every LDS-DMA is directly preceded by the instruction that writes m0, and nothing else
+    in the kernel reads m0."""
+    errors = []
+    ins = [ln.split(";")[0].strip() for ln in lines]
+    ins = [t for t in ins if t and not t.startswith(".") and not t.endswith(":")]
+    for i, t in enumerate(ins):
+        if t.startswith("global_load_lds"):
+            prev = ins[i - 1] if i else ""
+            if not re.match(r"s_(mov_b32|add_i32|add_u32)\s+m0,", prev):
+                errors.append(f"{name}: LDS-DMA not directly behind its m0 write: {prev!r} ; {t!r}")
+                break
+        elif re.search(r"\bm0\b", t):
+            ops = t.split(None, 1)[1] if " " in t else ""
+            if not re.match(r"m0\s*,", ops) or re.search(r",.*\bm0\b", ops):
+                errors.append(f"{name}: m0 is read by {t!r}")
+                break
+    return errors
+
+
 def check_gemm8(asm=None):
     asm = asm or device_asm("gemm8.hip")
     body, meta = kernels(asm)
@@ -194,6 +216,9 @@ def check_gemm8(asm=None):
         report.append((name, n_dma, n_wait, n_foreign))
     if not report:
         errors.append("no gemm8 kernel found")
+    for name, lines in body.items():
+        if "gemm8_kernel" in name:
+            errors += check_m0(name, lines)
     return report, errors
 
 
@@ -225,6 +250,7 @@ def check_attention(asm=None):
         n_bperm = sum(1 for ln in lines if ln.strip().startswith("ds_bpermute"))
         if n_swap < 1 or n_bperm > 1:
             errors.append(f"{name}: {n_swap} v_permlane32_swap, {n_bperm} ds_bpermute (expected the per-tile exchange on the VALU)")
+        errors += check_m0(name, lines)
         report.append((name, n_dma, sum(1 for ln in lines if "v_mfma" in ln), counted))
     if not report:
         errors.append("attn4p kernel not found")
