@@ -352,6 +352,11 @@ int mmada_set_option(const char* name, int value);
 size_t mmada_mfma_probe_bytes(void);
 int mmada_mfma_probe(const void* data, void* sink, int iters, int launches, void* stream, double* tflops_out, double* ms_out);
 
+/* ---- rounding probe (tests only) -----------------------------------------------------------------------------------------
+ * out[i] = the library's fp32 -> bf16 conversion (f2bf of csrc/common.h, used by every epilogue and elementwise kernel) of
+ * in[i]; tests/test_gpu_kernels.py sweeps all 2^32 bit patterns against torch's conversion. */
+int mmada_probe_f2bf(const float* in, uint16_t* out, int64_t n, void* stream);
+
 /* ---- tensor-parallel exchange inside the library (SURVEY.md §8b mmada_allreduce_init, §8e) ----------------------------
  * New design; the reference runs one replica (inference.py:83-85).  With tp_size > 1 the two row-parallel GEMMs of a block
  * (attn_out, ff_out; model/modeling_llada.py:741-744, 968-970) leave a partial [B*Lp, d] sum on every rank.  One exchange

@@ -311,6 +311,11 @@ int mmada_set_option(const char* name, int value) {
     return mm_fail("mmada_set_option: unknown option '%s'", name);
 }
 
+int mmada_probe_f2bf(const float* in, uint16_t* out, int64_t n, void* stream) {
+    if (!in || !out || n < 0) return mm_fail("mmada_probe_f2bf: bad argument");
+    return launch_f2bf_probe(in, out, (long long)n, (hipStream_t)stream);
+}
+
 size_t mmada_mfma_probe_bytes(void) { return (size_t)64 * 8 * 16 * 64 * 16; }
 
 int mmada_mfma_probe(const void* data, void* sink, int iters, int launches, void* stream, double* tflops_out, double* ms_out) {

@@ -95,4 +95,5 @@ int launch_image_commit(int64_t* ids, int B, int L, const int32_t* pos_map, int 
 
 // probe.hip: MFMA-only diagnostic (attainable roof at the sustained clock on random data)
 void mfma_probe_set_variant(int v);
+int launch_f2bf_probe(const float* in, bf16_t* out, long long n, hipStream_t s);
 int launch_mfma_probe(const bf16_t* data, float* sink, int iters, int launches, hipStream_t s, double* tflops_out, double* ms_out);

@@ -159,3 +159,16 @@ int launch_mfma_probe(const bf16_t* data, float* sink, int iters, int launches, 
     if (ms_out) *ms_out = ms;
     return 0;
 }
+
+// ---- rounding probe: out[i] = f2bf(in[i]) (tests: every fp32 bit pattern against torch) --------------------------------
+namespace {
+__global__ __launch_bounds__(256) void f2bf_probe_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = f2bf(in[i]);
+}
+}  // namespace
+int launch_f2bf_probe(const float* in, bf16_t* out, long long n, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(f2bf_probe_kernel, dim3(8192), dim3(256), 0, s, in, out, n);
+    MM_CHECK_HIP(hipGetLastError());
+    return 0;
+}

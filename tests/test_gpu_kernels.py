@@ -99,6 +99,25 @@ def test_rmsnorm(rows, d):
     assert (bits(out) != bits(ref)).float().mean() < 5e-3
 
 
+def test_f2bf_matches_torch_on_every_bit_pattern():
+    """f2bf (csrc/common.h: the hardware conversion v_cvt_pk_bf16_f32 since round 4) against torch's fp32 -> bf16 cast on
+    ALL 2^32 fp32 bit patterns: equal bits for every finite value (denormals included) and both infinities; a NaN stays a
+    NaN (payloads may differ: torch canonicalises)."""
+    lib = abi.lib()
+    chunk = 1 << 27
+    for c in range(32):
+        bits = torch.arange(c * chunk, (c + 1) * chunk, dtype=torch.int64, device=DEV).to(torch.int32)  # wraps to the signed pattern
+        x = bits.view(torch.float32)
+        out = torch.empty(chunk, dtype=torch.int16, device=DEV)
+        abi.check(lib.mmada_probe_f2bf(x.data_ptr(), out.data_ptr(), chunk, st()), "probe_f2bf")
+        ref = x.to(torch.bfloat16).view(torch.int16)
+        nan = torch.isnan(x)
+        assert torch.equal(out[~nan], ref[~nan]), f"chunk {c}: {int((out[~nan] != ref[~nan]).sum())} finite values differ"
+        if bool(nan.any()):
+            assert bool(torch.isnan(out[nan].view(torch.bfloat16)).all()), f"chunk {c}: a NaN became a number"
+        del bits, x, out, ref, nan
+
+
 # ------------------------------------------------------------------------------------------------- GEMM configurations
 @pytest.mark.parametrize("M,N,K", [(2440, 1536, 512), (648, 1024, 1024), (8, 256, 256), (4880, 512, 4096), (328, 8200, 256),
                                    (624, 512, 256), (632, 512, 256), (5000, 256, 256)])
