@@ -177,7 +177,10 @@ int launch_cfg(const GemmArgs& g, hipStream_t s) {
 // Both kernels accumulate a K-tile at a time in the same order with the same MFMA, so the choice never changes a bit of
 // the result (tests/test_gpu_kernels.py::test_gemm_configurations_are_bit_identical).
 constexpr float OLD_SCALE = 1.0f;                    // 16-wave model vs this round's measurements
-constexpr float A8 = 0.00483f, D0 = 6.0f, D1 = 0.03f;  // 8-phase kernel: us per (row of 256 columns x K-tile), per round
+// 8-phase kernel: us per (row of 256 columns x K-tile), per round.  D0 / D1 re-fitted in round 4 (6.0 / 0.03 before): the epilogues
+// lost half of their instructions with the hardware fp32 -> bf16 conversion (tools/fit_gemm8_cost.py on
+// profiles/r04_gemm8_sweep_final.txt; with the old constants the short-K tensor-parallel shapes went to the slower 16-wave kernel)
+constexpr float A8 = 0.00483f, D0 = 2.7f, D1 = 0.025f;
 constexpr float H8[GEMM8_NCFG] = {1.0f, 1.0f, 1.08f, 1.08f};
 struct Plan { bool p8; int code; };  // code: GEMM8_* configuration or the 16-wave kernel's BM
 
