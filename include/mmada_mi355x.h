@@ -342,6 +342,9 @@ int mmada_profile_end(mmada_handle* h, int32_t* count_out /*[5]*/, double* ms_ou
  *                    one of <= 320 cover M (M = B * 2440: 5 % fewer MFMAs in all but the last row tile); 0: full height
  *   "probe_variant"  MFMA shape / occupancy of mmada_mfma_probe (tools/probe_variants.py) */
 int mmada_set_option(const char* name, int value);
+/* The tile configuration the GEMM planner picks for a plain [M, K] x [N, K]^T product (host arithmetic, no launch): 0..3 = the
+ * 8-phase configurations in the order above, 1000 + BM = the 16-wave kernel, -1 = unsupported shape.  Honours "gemm_config". */
+int mmada_gemm_plan(int M, int N, int K);
 
 /* ---- attainable-MFMA probe (bench.py's roofline.attainable_tflops; measurement only, no reference counterpart) -----
  * Runs `launches` launches of an MFMA-only kernel (v_mfma_f32_16x16x32_bf16 on register-resident operand fragments taken

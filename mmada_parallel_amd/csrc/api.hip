@@ -311,6 +311,8 @@ int mmada_set_option(const char* name, int value) {
     return mm_fail("mmada_set_option: unknown option '%s'", name);
 }
 
+int mmada_gemm_plan(int M, int N, int K) { return gemm_plan_code(M, N, K); }
+
 int mmada_probe_f2bf(const float* in, uint16_t* out, int64_t n, void* stream) {
     if (!in || !out || n < 0) return mm_fail("mmada_probe_f2bf: bad argument");
     return launch_f2bf_probe(in, out, (long long)n, (hipStream_t)stream);

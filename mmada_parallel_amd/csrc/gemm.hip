@@ -248,6 +248,16 @@ int launch_t(const GemmArgs& g, hipStream_t s) {
 
 void gemm_force_config(int code) { g_force = code; }
 
+// what the planner would launch for a plain [M, K] x [N, K]^T product (host arithmetic only): 0..3 = GEMM8_* configuration,
+// 1000 + BM = the 16-wave kernel — tests/test_host_logic.py holds it against the committed sweep table
+int gemm_plan_code(int M, int N, int K) {
+    GemmArgs g{};
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N;
+    if (M <= 0 || N <= 0 || K <= 0 || K % BK) return -1;
+    const Plan p = plan(g);
+    return p.p8 ? p.code : 1000 + p.code;
+}
+
 // 8 zero rows of up to ZERO_ROW_ELEMS / 8 elements per device (never freed: process lifetime): the source of the A rows of
 // the last row tile that lie beyond M
 static int zero_rows_for_device(const bf16_t** out) {

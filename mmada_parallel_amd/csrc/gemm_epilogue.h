@@ -345,5 +345,6 @@ int launch_gemm8(int epi, int cfg, const GemmArgs& g, hipStream_t s);
 // Measurement hook (tools/gemm_sweep.py, tests): force one configuration for every following launch of this process.
 //   -1: automatic (default);  0..3: GEMM8_* configuration;  1000 + BM: the 16-wave kernel with that row-tile height.
 void gemm_force_config(int code);
+int gemm_plan_code(int M, int N, int K);  // the planner's pick for a plain product: 0..3 or 1000 + BM; -1: unsupported shape
 // short row tiles of the 320-row configurations (gemm8.hip) on / off; on by default
 void gemm8_set_short_tiles(int on);

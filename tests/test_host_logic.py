@@ -317,3 +317,39 @@ def test_bench_self_launch_relays_the_line_and_the_exit_code(tmp_path):
     assert line["n_gpus"] == 2 and line["argv"] == ["--gpus", "2", "--steps", "1"]
     p = subprocess.run([sys.executable, "-c", drv, str(bad)], capture_output=True, text=True, timeout=300, env=env)
     assert p.returncode != 0 and p.stdout.strip() == ""
+
+
+def test_gemm_planner_picks_the_measured_best_on_the_committed_sweep():
+    """csrc/gemm.hip prices every tile configuration with a fitted cost model.  The committed sweep (profiles/
+    r04_gemm8_sweep_final.txt: 32 (shape, M) points of the TP = 1 / 2 / 4 / 8 projection shapes, all 8-phase configurations and two
+    16-wave ones measured side by side) is the evidence for its constants: on every point the planner's pick (mmada_gemm_plan — host
+    arithmetic, no GPU) must be a configuration whose MEASURED rate is within 3 % of the best measured one."""
+    import os
+
+    from mmada_parallel_amd import abi
+
+    shapes = {"qkv": (12288, 4096), "o": (4096, 4096), "gateup": (24576, 4096), "down": (4096, 12288),
+              "qkv2": (6144, 4096), "o2": (4096, 2048), "gu2": (12288, 4096), "dn2": (4096, 6144),
+              "qkv4": (3072, 4096), "o4": (4096, 1024), "gu4": (6144, 4096), "dn4": (4096, 3072),
+              "qkv8": (1536, 4096), "o8": (4096, 512), "gu8": (3072, 4096), "dn8": (4096, 1536)}
+    code_of = {300: 0, 301: 1, 302: 2, 303: 3, 1320: 1320, 1256: 1256}
+    lib = abi.lib()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cols, points = None, 0
+    for ln in open(os.path.join(root, "profiles", "r04_gemm8_sweep_final.txt")):
+        p = ln.split()
+        if not p or ln.startswith("#"):
+            continue
+        if p[0] == "shape":
+            cols = [int(x[1:]) for x in p[2:] if x.startswith("v")]
+            continue
+        if p[0] not in shapes:
+            continue
+        M, (N, K) = int(p[1]), shapes[p[0]]
+        tf = {code_of[v]: float(x) for v, x in zip(cols, p[2:]) if v in code_of}
+        pick = lib.mmada_gemm_plan(M, N, K)
+        assert pick in tf, f"{p[0]} M={M}: the planner picks configuration {pick}, which the sweep did not measure"
+        assert tf[pick] >= 0.97 * max(tf.values()), f"{p[0]} M={M}: pick {pick} at {tf[pick]} TF, best {max(tf.values())} TF ({tf})"
+        points += 1
+    assert points == 32
+    assert lib.mmada_gemm_plan(2440, 4096, 100) == -1   # K is not a multiple of the K-tile
