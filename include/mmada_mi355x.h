@@ -338,6 +338,8 @@ int mmada_profile_end(mmada_handle* h, int32_t* count_out /*[5]*/, double* ms_ou
  *   "attention_form" -1 automatic (default: MMADA_ATTN_FORM or 1); 0 the round-2 issue order; 1 software-pipelined matrix
  *                    blocks (fragments prefetched in registers, pinned issue order); 2 attention64 (64 query rows per wave,
  *                    one wave per SIMD, hand-owned accumulator file)
+ *   "gemm_silu_lut"  1 (default): the 8-phase SwiGLU epilogue reads SiLU of the bf16 gate value from a 10-KiB table in the LDS (filled on
+ *                    the device by the function it replaces; untabulated values are evaluated); 0: always evaluate
  *   "gemm_short_tiles" 1 (default): the 320-row configurations use a row-tile pitch of 304 when ntm - 1 tiles of 304 rows and
  *                    one of <= 320 cover M (M = B * 2440: 5 % fewer MFMAs in all but the last row tile); 0: full height
  *   "probe_variant"  MFMA shape / occupancy of mmada_mfma_probe (tools/probe_variants.py) */
@@ -431,6 +433,9 @@ int mmada_graph_destroy(mmada_graph* g);
 
 /* C[M,N] = A[M,K] · W[N,K]^T, bf16 in / fp32 accumulate / bf16 out (F.linear without bias). */
 int mmada_gemm_bt(const void* A, const void* W, void* C, int M, int N, int K, void* stream);
+/* C[M, N/2] = silu(bf16(A·Wg^T)) * bf16(A·Wu^T) with W in the packed gate/up row order of the library (rows in groups of 32:
+ * 16 rows of ff_proj, then the matching 16 rows of up_proj — model/modeling_llada.py:962-968 fused); tests of the SwiGLU epilogue. */
+int mmada_gemm_swiglu_bt(const void* A, const void* W, void* C, int M, int N, int K, void* stream);
 /* RMSLayerNorm.forward (model/modeling_llada.py:301-329): out = w * bf16(x * rsqrt(mean(x²)+eps)). */
 int mmada_rmsnorm(const void* x, const void* w, void* out, int rows, int d, float eps, void* stream);
 /* Unmasked non-causal SDPA over [B,H,L,128] q/k/v (bf16, contiguous) → out [B,L,H*128]

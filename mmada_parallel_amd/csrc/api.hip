@@ -305,10 +305,19 @@ int mmada_profile_end(mmada_handle* h, int32_t* count_out, double* ms_out, doubl
 int mmada_set_option(const char* name, int value) {
     if (!name) return mm_fail("mmada_set_option: null name");
     if (!strcmp(name, "gemm_config")) { gemm_force_config(value); return 0; }
+    if (!strcmp(name, "gemm_silu_lut")) { gemm_set_silu_lut(value); return 0; }
     if (!strcmp(name, "gemm_short_tiles")) { gemm8_set_short_tiles(value); return 0; }
     if (!strcmp(name, "attention_form")) { attention_force_form(value); return 0; }
     if (!strcmp(name, "probe_variant")) { mfma_probe_set_variant(value); return 0; }
     return mm_fail("mmada_set_option: unknown option '%s'", name);
+}
+
+int mmada_gemm_swiglu_bt(const void* A, const void* W, void* C, int M, int N, int K, void* stream) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0 || N % 64) return mm_fail("mmada_gemm_swiglu_bt: bad argument");
+    GemmArgs g{};
+    g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.C = (bf16_t*)C;
+    g.M = M; g.N = N; g.K = K; g.lda = K; g.ldw = K; g.ldc = N / 2;
+    return launch_gemm(EPI_SWIGLU, g, (hipStream_t)stream);
 }
 
 int mmada_gemm_plan(int M, int N, int K) { return gemm_plan_code(M, N, K); }

@@ -276,8 +276,47 @@ static int zero_rows_for_device(const bf16_t** out) {
     return 0;
 }
 
+// ---- the SiLU table of the SwiGLU epilogue (gemm_epilogue.h: SiluLut), one per device, filled by the function it replaces ----
+__global__ void silu_lut_kernel(uint16_t* t) {
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned)gemm_detail::SiluLut::ENTRIES) return;
+    const unsigned key = idx >> 1, sign = idx & 1u;
+    uint16_t v = 0;
+    if (key < gemm_detail::SiluLut::NKEY) {
+        const unsigned bits = (sign << 15) | (key + gemm_detail::SiluLut::E0);
+        v = f2bf(gemm_detail::silu_bf16(__uint_as_float(bits << 16)));
+    }
+    t[idx] = v;
+}
+static int g_silu_lut = -1;  // -1: read MMADA_GEMM_SILU_LUT once (default on)
+static int silu_lut_for_device(const uint16_t** out, hipStream_t s) {
+    static uint16_t* lut[16] = {};
+    *out = nullptr;
+    if (g_silu_lut < 0) {
+        const char* e = getenv("MMADA_GEMM_SILU_LUT");
+        g_silu_lut = e && e[0] == '0' ? 0 : 1;
+    }
+    if (!g_silu_lut) return 0;
+    int dev = 0;
+    MM_CHECK_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 16) return 0;
+    if (!lut[dev]) {   // first SwiGLU launch on this device (eager: a hipMalloc cannot be captured, like the zero rows below)
+        uint16_t* p = nullptr;
+        MM_CHECK_HIP(hipMalloc(&p, gemm_detail::SiluLut::BYTES));
+        hipLaunchKernelGGL(silu_lut_kernel, dim3((gemm_detail::SiluLut::ENTRIES + 255) / 256), dim3(256), 0, s, p);   // ordered before the GEMM
+        MM_CHECK_HIP(hipGetLastError());
+        MM_CHECK_HIP(hipStreamSynchronize(s));   // once per device: another stream's first SwiGLU launch must not overtake the fill
+        lut[dev] = p;
+    }
+    *out = lut[dev];
+    return 0;
+}
+void gemm_set_silu_lut(int on) { g_silu_lut = on != 0 ? 1 : 0; }
+
 int launch_gemm(int epi, const GemmArgs& g_in, hipStream_t s) {
     GemmArgs g = g_in;
+    g.silu_lut = nullptr;
+    if (epi == EPI_SWIGLU && silu_lut_for_device(&g.silu_lut, s)) return 1;
     // the 16-wave kernel reads K zeros, the 8-phase kernel a block of 8 rows x lda
     if (g.K <= ZERO_ROW_ELEMS / 8 && g.lda <= ZERO_ROW_ELEMS / 8 && zero_rows_for_device(&g.zero_row)) return 1;
     if (g.M <= 0 || g.N <= 0) return 0;

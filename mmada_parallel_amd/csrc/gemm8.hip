@@ -104,7 +104,7 @@ struct Gemm8 {
     static constexpr bool CAN_DROP = WM == 2 && FA1 >= 2 && BM == 320;
     static constexpr int SHORT_BM = BM - 16;
     static_assert(NPB % 8 == 0 && (RA0 == 0 || RA1 == 0 || RA0 == RA1) && NPA0 <= 24 && NPA1 <= 24, "piece split");
-    static_assert(LDS <= 160 * 1024, "LDS");
+    static_assert(LDS + SiluLut::BYTES <= 160 * 1024, "LDS (K-tile buffers + the SwiGLU epilogue's SiLU table)");
 
     const char* Ab;  // wave-uniform byte bases of the A / W panels of this output tile
     const char* Wb;
@@ -120,6 +120,8 @@ struct Gemm8 {
     int alds[2][3], wlds[2][2];       // wave-uniform LDS byte offsets of those pieces in buffer 0
     int ra[2], rb[2];                 // per-lane LDS read offsets [k-step] of fragment 0 in buffer 0 (the other fragments
                                       // and the second buffer are immediates)
+    const char* lut_src;              // SwiGLU builds: the SiLU table in device memory (null: none), staged behind the K-tile buffers
+    int lut_wave;
     bf16x8 af[FA0][2], bf0[FB][2], bf1[FB][2];
     f32x4 acc[FM][FN];
 
@@ -313,6 +315,17 @@ struct Gemm8 {
         // the vector-memory queue is empty here at run time; saying so keeps the static check of the counted waits
         // (tools/isa_check.py) independent of how the compiler lays the two code paths out
         wait_vm<0>();
+        if (lut_src) {
+            // the SiLU table of the SwiGLU epilogue: ten 1-KiB pieces requested BEFORE the pipeline's first piece — the oldest
+            // entries of the vector-memory queue, so every counted wait below also covers them and none has to change; the
+            // epilogue reads the table a whole main loop (and many barriers) later
+            unsigned lane16 = (unsigned)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) * 16u;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int p = lut_wave + 8 * i;
+                if (p < SiluLut::PIECES) dma16(lut_src + p * 1024, lane16, LDS + p * 1024);
+            }
+        }
         stage_a<0, 0, NA0>(0); stage_w<0, 0>(0); stage_w<0, 1>(0); stage_a<0, 1, NA1>(0);
         if (BAL) { stage_w<1, 0>(1); stage_a<1, 0, NA0>(1); }
         else { stage_a<1, 0, NA0>(1); stage_w<1, 0>(1); }
@@ -363,7 +376,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     const int m_lim = short_tile ? m0 + G::SHORT_BM : g.M;   // the epilogue's view: rows of this tile only
     const bool drop = short_tile && wave / G::WN == G::WM - 1;
     G k;
+    // SwiGLU: the SiLU table (gemm_epilogue.h: SiluLut) goes into the LDS behind the K-tile buffers (run() requests it)
+    const bool use_lut = EPI == EPI_SWIGLU && g.silu_lut != nullptr;
+    const int lut_lds = use_lut ? G::LDS : -1;
     k.init(g, m0, n0, wave, threadIdx.x & 63);
+    k.lut_src = use_lut ? (const char*)g.silu_lut : nullptr;
+    k.lut_wave = wave;
     const int nk = g.K / BK;
     // Up to four self-contained code paths (a wave moves one LDS-DMA piece more per A half-tile or not; operand roles
     // swapped or not): they never rejoin with live accumulators — each runs its own epilogue, which recomputes the lane
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     do {                                                                                            \
         k.template run<A0, A1, SWP, DRP>(nk, wave >> 2);                                            \
         const int lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));        \
-        if (SWP) gemm_epilogue_t<EPI, G::TM, G::TN, G::WN>(g, m0, n0, k.acc, wave, lane, m_lim);         \
+        if (SWP) gemm_epilogue_t<EPI, G::TM, G::TN, G::WN>(g, m0, n0, k.acc, wave, lane, m_lim, lut_lds); \
         else gemm_epilogue<EPI, G::TM, G::TN, G::WN>(g, m0, n0, k.acc, wave, lane, m_lim);               \
     } while (0)
 #define G8_PATH(A0, A1, SWP)                                                                        \
@@ -401,13 +419,14 @@ template <int EPI, class G>
 int launch_cfg8(const GemmArgs& g, hipStream_t s) {
     auto fn = gemm8_kernel<EPI, G>;
     static MmOncePerDevice attr_set;
-    MM_ONCE_PER_DEVICE(attr_set, MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS)));
+    constexpr int LDS_BYTES = G::LDS + (EPI == EPI_SWIGLU ? SiluLut::BYTES : 0);
+    MM_ONCE_PER_DEVICE(attr_set, MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES)));
     const int ntm = (g.M + G::BM - 1) / G::BM, ntn = (g.N + G::BN - 1) / G::BN;
     GemmArgs ga = g;
     // short row tiles when ntm - 1 tiles of 304 rows and one of <= 320 cover M (same tile count, 5 % fewer MFMAs in all
     // but the last row tile): M = 2440 -> 7 x 304 + 312, M = 4880 -> 15 x 304 + 320
     ga.row_drop = G::CAN_DROP && short_tiles_on() && ntm >= 2 && (ntm - 1) * G::SHORT_BM + G::BM >= g.M ? 1 : 0;
-    hipLaunchKernelGGL(fn, dim3(ntm * ntn), dim3(512), G::LDS, s, ga);
+    hipLaunchKernelGGL(fn, dim3(ntm * ntn), dim3(512), LDS_BYTES, s, ga);
     MM_CHECK_HIP(hipGetLastError());
     return 0;
 }

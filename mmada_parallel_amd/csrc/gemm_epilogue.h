@@ -28,6 +28,23 @@ MM_DEVICE float silu_bf16(float g) {
     return bfround(g / (1.0f + expf(-g)));
 }
 
+// SiLU as a table (round 4).  The SwiGLU epilogue applies silu_bf16 to a value that has just been rounded to bf16: a function of
+// 16 bits.  Evaluating it costs ~25 VALU instructions per output (expf, an IEEE division, a rounding), 80 outputs per lane and
+// tile; the table costs 5 + one 2-byte LDS read.  Only the exponents that occur are tabulated: |x| in [2^-14, 2^5), both signs —
+// 19 x 128 x 2 = 4 864 entries, padded to 5 120 (10 KiB, ten 1-KiB LDS-DMA pieces), which fits beside the K-tile buffers of every
+// tile configuration.  Anything else (tiny, huge, Inf, NaN: a wave-uniform test over four outputs) takes the evaluating path.
+// The table is filled ON THE DEVICE by silu_bf16 itself (gemm.hip: silu_lut_kernel), so both paths return the same bits by
+// construction; tests/test_gpu_kernels.py::test_swiglu_table_is_bit_identical sweeps all 65 536 gate values through both.
+struct SiluLut {
+    static constexpr unsigned E0 = 113u << 7;       // bf16 bits (sign cleared) of 2^-14
+    static constexpr unsigned NKEY = 19u * 128u;    // [2^-14, 2^5)
+    static constexpr int ENTRIES = 5120, BYTES = ENTRIES * 2, PIECES = BYTES / 1024;
+    // entry index of a bf16 value, or >= 2 * NKEY when it is not tabulated
+    static MM_DEVICE unsigned key(unsigned bits) { return (bits & 0x7fffu) - E0; }
+    static MM_DEVICE unsigned index(unsigned bits) { return (key(bits) << 1) | (bits >> 15); }
+};
+typedef __attribute__((address_space(3))) const uint16_t* lds_u16_ptr;
+
 // Tile sequence number -> (row tile, column tile): grouped order, GN column tiles (1024 columns) x all row tiles per group, so
 // workgroups with neighbouring sequence numbers (same XCD after xcd_remap) share A and W panels in their L2.
 template <int GN = 4>
@@ -202,7 +219,8 @@ MM_DEVICE void swap_halves16(uint32_t& a, uint32_t& b) {
 MM_DEVICE int run8_col(int lq) { return (lq & 1) * 16 + (lq >> 1) * 8; }
 
 template <int EPI, int TM, int TN, int WN>
-MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[TM / 16][TN / 16], int wave, int lane, int m_lim) {
+MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[TM / 16][TN / 16], int wave, int lane, int m_lim,
+                                int lut_lds = -1 /* LDS byte address of the SiLU table, or -1 */) {
     constexpr int FM = TM / 16, FN = TN / 16;
     static_assert(TN % 32 == 0, "fused epilogues pair adjacent 16-column fragments");
     const int wm = wave / WN, wn = wave % WN;
@@ -259,9 +277,23 @@ MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[T
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     float o[4];
+                    uint32_t gb[4];
+                    bool untabulated = false;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        o[r] = silu_bf16(bfround(acc[mi][2 * (q2 + u)][r])) * bfround(acc[mi][2 * (q2 + u) + 1][r]);
+                    for (int r = 0; r < 4; ++r) {
+                        gb[r] = f2bf(acc[mi][2 * (q2 + u)][r]);
+                        untabulated |= SiluLut::key(gb[r]) >= SiluLut::NKEY;
+                    }
+                    if (lut_lds >= 0 && !__any(untabulated)) {   // wave-uniform: all 256 gate values of this step are tabulated
+                        uint32_t sv[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sv[r] = *(lds_u16_ptr)(uint32_t)(lut_lds + (int)(SiluLut::index(gb[r]) << 1));
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = __uint_as_float(sv[r] << 16) * bfround(acc[mi][2 * (q2 + u) + 1][r]);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = silu_bf16(__uint_as_float(gb[r] << 16)) * bfround(acc[mi][2 * (q2 + u) + 1][r]);
+                    }
                     pk[u][0] = pack_bf2(o[0], o[1]);
                     pk[u][1] = pack_bf2(o[2], o[3]);
                 }
@@ -348,3 +380,5 @@ void gemm_force_config(int code);
 int gemm_plan_code(int M, int N, int K);  // the planner's pick for a plain product: 0..3 or 1000 + BM; -1: unsupported shape
 // short row tiles of the 320-row configurations (gemm8.hip) on / off; on by default
 void gemm8_set_short_tiles(int on);
+// SiLU table of the SwiGLU epilogue (8-phase kernel) on / off; on by default
+void gemm_set_silu_lut(int on);

@@ -40,6 +40,9 @@ struct GemmArgs {
     // q_mask quirk with caching() off, :714-716,416-428).
     const int32_t* pos_map;
     int Lq, q_pos_shift;
+    // EPI_SWIGLU in the 8-phase kernel: SiLU of a bf16 value as a table (gemm_epilogue.h: SiluLut) in device memory, or null =
+    // evaluate it (set by launch_gemm)
+    const uint16_t* silu_lut;
     int row_drop;      // set by gemm8's launcher only: row tiles of pitch BM - 16 (gemm8.hip, "short row tiles")
 };
 

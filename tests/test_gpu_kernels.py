@@ -118,6 +118,63 @@ def test_f2bf_matches_torch_on_every_bit_pattern():
         del bits, x, out, ref, nan
 
 
+def test_swiglu_table_is_bit_identical():
+    """The 8-phase SwiGLU epilogue reads SiLU of the bf16-rounded gate value from a table (gemm_epilogue.h: SiluLut, filled on the
+    device by the function it replaces; untabulated values take the evaluating path).  With A = identity the pre-activations
+    are the weight entries themselves, so every finite bf16 bit pattern goes through the epilogue as a gate value (tabulated ones
+    in whole waves, the rest — zeros, denormals, tiny, huge — mixed in and in waves of their own; Inf / NaN in a third run), against
+    two up values.  Table on / table off / the 16-wave kernel (always evaluates) must agree bit for bit, every tile configuration, and the
+    finite results must be torch's silu(gate) * up rounded the way the reference rounds (bf16 after the Linear, after SiLU, after
+    the product)."""
+    lib = abi.lib()
+    K = M = 256
+    A = torch.eye(M, K, dtype=torch.bfloat16, device=DEV)
+    pat = torch.arange(65536, dtype=torch.int32, device=DEV).to(torch.int16).view(torch.bfloat16)     # every bf16 value
+    perm = torch.randperm(65536, generator=torch.Generator().manual_seed(5)).to(DEV)
+    # 0 x Inf = NaN: a non-finite weight poisons its whole column of A·W^T, so the sweeps use the 65 280 finite patterns (the
+    # other 256 slots hold 1.0) and a third run keeps Inf / NaN in (bit identity of the paths only)
+    finite = torch.where(torch.isfinite(pat.float()), pat, torch.ones_like(pat))
+    # the table's own domain, |x| in [2^-14, 2^5): 4 864 patterns, tiled and shuffled — every wave of this run takes the table path
+    # (in the full sweeps above almost every wave holds an untabulated value and evaluates)
+    key = torch.arange(65536, dtype=torch.int32, device=DEV) % (2 * 19 * 128)
+    tab = (((key & 1) << 15) | ((key >> 1) + (113 << 7))).to(torch.int16).view(torch.bfloat16)
+    for gate_vals, up_val, against_torch in ((finite, 1.0, True), (finite[perm], -0.37109375, True), (pat[perm], 1.0, False),
+                                             (tab[perm], 1.0, True), (tab, 2.5, True)):
+        # pre-activation P[m][n] = W[n][m]; columns come in groups of 32 = [16 gate | 16 up]; 256 groups x 16 x 256 rows = 65 536 gates
+        N = 2 * 256
+        gate = gate_vals.view(256, 256)                      # gate[m][j]: row m, gate column j
+        W = torch.empty(N, K, dtype=torch.bfloat16, device=DEV)
+        Wv = W.view(N // 32, 2, 16, K)                        # [group][gate | up][16][K]
+        Wv[:, 0] = gate.t().contiguous().view(16, 16, K)      # gate column j = 16 * group + i  ->  W row (group, 0, i)
+        Wv[:, 1] = up_val
+        outs = {}
+        try:
+            for name, cfg, lut in (("table", 0, 1), ("evaluated", 0, 0), ("table 256x256", 1, 1), ("table 160x256", 2, 1),
+                                   ("table 320x128", 3, 1), ("16-wave", 1256, 1)):
+                abi.check(lib.mmada_set_option(b"gemm_config", cfg), "set_option")
+                abi.check(lib.mmada_set_option(b"gemm_silu_lut", lut), "set_option")
+                C = torch.full((M, N // 2), float("nan"), dtype=torch.bfloat16, device=DEV)
+                abi.check(lib.mmada_gemm_swiglu_bt(A.data_ptr(), W.data_ptr(), C.data_ptr(), M, N, K, st()), "swiglu")
+                torch.cuda.synchronize()
+                outs[name] = C
+        finally:
+            lib.mmada_set_option(b"gemm_config", -1)
+            lib.mmada_set_option(b"gemm_silu_lut", 1)
+        base = outs["evaluated"].view(torch.int16)
+        for name, C in outs.items():
+            assert torch.equal(C.view(torch.int16), base), f"{name}: {int((C.view(torch.int16) != base).sum())} of 65536 outputs differ"
+        if not against_torch:
+            continue
+        g32 = gate.float()
+        ref = (torch.nn.functional.silu(g32).to(torch.bfloat16).float() * up_val).to(torch.bfloat16)
+        fin = torch.isfinite(ref.float()) & torch.isfinite(g32) & (ref.float().abs() > 1e-30)   # sanity check on normal results only
+        got = outs["table"]
+        # SiLU evaluated in fp32 by two libms may round a half-way case differently: allow one bf16 ulp on a handful, none elsewhere
+        d = (got.float() - ref.float()).abs()[fin]
+        ulp = (ref.float().abs()[fin] * 2.0 ** -7).clamp_min(1e-40)
+        assert bool((d <= ulp).all()) and float((d > 0).float().mean()) < 2e-3, (float(d.max()), float((d > 0).float().mean()))
+
+
 # ------------------------------------------------------------------------------------------------- GEMM configurations
 @pytest.mark.parametrize("M,N,K", [(2440, 1536, 512), (648, 1024, 1024), (8, 256, 256), (4880, 512, 4096), (328, 8200, 256),
                                    (624, 512, 256), (632, 512, 256), (5000, 256, 256)])
