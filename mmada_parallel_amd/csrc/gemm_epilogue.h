@@ -44,6 +44,10 @@ struct SiluLut {
     static MM_DEVICE unsigned index(unsigned bits) { return (key(bits) << 1) | (bits >> 15); }
 };
 typedef __attribute__((address_space(3))) const uint16_t* lds_u16_ptr;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wint-to-pointer-cast"
+MM_DEVICE uint32_t lds_u16(int byte_off) { return *(lds_u16_ptr)(uint32_t)byte_off; }   // LDS addresses are plain integers here (gemm8.hip)
+#pragma clang diagnostic pop
 
 // Tile sequence number -> (row tile, column tile): grouped order, GN column tiles (1024 columns) x all row tiles per group, so
 // workgroups with neighbouring sequence numbers (same XCD after xcd_remap) share A and W panels in their L2.
@@ -287,7 +291,7 @@ MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[T
                     if (lut_lds >= 0 && !__any(untabulated)) {   // wave-uniform: all 256 gate values of this step are tabulated
                         uint32_t sv[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) sv[r] = *(lds_u16_ptr)(uint32_t)(lut_lds + (int)(SiluLut::index(gb[r]) << 1));
+                        for (int r = 0; r < 4; ++r) sv[r] = lds_u16(lut_lds + (int)(SiluLut::index(gb[r]) << 1));
 #pragma unroll
                         for (int r = 0; r < 4; ++r) o[r] = __uint_as_float(sv[r] << 16) * bfround(acc[mi][2 * (q2 + u) + 1][r]);
                     } else {
