@@ -89,7 +89,9 @@ int mmada_bind_layer(mmada_handle* h, int layer,
 /* Bytes of activation workspace needed for a forward of B sequences of length L (all equal length: the
  * reference never masks padding). */
 size_t mmada_workspace_bytes(const mmada_handle* h, int B, int L);
-/* Caller-owned device buffer (>= mmada_workspace_bytes for the largest (B,L) used), 256-byte aligned. */
+/* Caller-owned device buffer (>= mmada_workspace_bytes for the largest (B,L) used), 256-byte aligned.  The call zeroes the
+ * buffer's first 64 KiB (a synchronous hipMemset): the arrival counters of the attention kernel's key split, which every
+ * launch leaves at zero again.  Nobody else may write there while the handle owns the buffer. */
 int mmada_set_workspace(mmada_handle* h, void* ws, size_t bytes);
 
 /* ---- transformer forward -------------------------------------------------------------------------------------
@@ -331,8 +333,14 @@ int mmada_profile_begin(mmada_handle* h, int layer);
 int mmada_profile_end(mmada_handle* h, int32_t* count_out /*[5]*/, double* ms_out /*[5]*/, double* flops_out /*[5]*/);
 
 /* ---- measurement / test switches (process-wide; no reference counterpart) --------------------------------------------
- * Every choice below is between kernels that produce BIT-IDENTICAL results (tests/test_gpu_kernels.py); the switches exist
- * so that sweeps and A/B tests can pin one.
+ * Every choice below EXCEPT "attention_split" is between kernels that produce BIT-IDENTICAL results
+ * (tests/test_gpu_kernels.py); the switches exist so that sweeps and A/B tests can pin one.
+ *   "attention_split" 1 (default): sequences of more than 2048 rows cut the KEYS of their last query tiles (rows >= 2048: the
+ *                    tiles beyond the whole rounds 32 heads x 16 tiles fill) 16 / n_tiles ways; fp32 partials, combined in
+ *                    split order by the last workgroup to arrive (csrc/attention.h: attn_split_plan — a function of L alone, so
+ *                    batch invariance and the consumed-row window's bit identity hold).  0: every query tile walks every key
+ *                    (the rows >= 2048 then differ in the last bf16 bit of some outputs: another fp32 summation order)
+ *   "attention_skip_idle" 1 (default): waves without a live query row skip their matrix blocks; 0: they compute and discard
  *   "gemm_config"    -1 automatic (default: the cost model of csrc/gemm.hip); 0..3 the 8-phase kernel's tile configuration
  *                    (320x256, 256x256, 160x256, 320x128); 1000 + BM the 16-wave kernel with that row-tile height
  *   "attention_form" -1 automatic (default: MMADA_ATTN_FORM or 1); 0 the round-2 issue order; 1 software-pipelined matrix
@@ -342,7 +350,12 @@ int mmada_profile_end(mmada_handle* h, int32_t* count_out /*[5]*/, double* ms_ou
  *                    the device by the function it replaces; untabulated values are evaluated); 0: always evaluate
  *   "gemm_short_tiles" 1 (default): the 320-row configurations use a row-tile pitch of 304 when ntm - 1 tiles of 304 rows and
  *                    one of <= 320 cover M (M = B * 2440: 5 % fewer MFMAs in all but the last row tile); 0: full height
- *   "probe_variant"  MFMA shape / occupancy of mmada_mfma_probe (tools/probe_variants.py) */
+ *   "probe_variant"  MFMA shape / occupancy of mmada_mfma_probe (tools/probe_variants.py)
+ *   "gemm_tile_order" 0 (default): the 8-phase kernel walks bands of 1024 columns, all row tiles per band; GM * 100 + GN: groups of GM
+ *                    row tiles x GN column tiles per XCD-round (the FETCH_SIZE sweep, tools/gemm_sweep.py --order)
+ *   "tp_allow_single_rank" 1: mmada_comm_create accepts tp_size == 1 and mmada_forward_body runs a connected one-rank handle through
+ *                    the tensor-parallel path (every line of the RCCL / pull transports executes; bit-identical to the plain
+ *                    forward: tests/test_gpu_tp.py).  0 (default): tp_size must be 2..8 */
 int mmada_set_option(const char* name, int value);
 /* The tile configuration the GEMM planner picks for a plain [M, K] x [N, K]^T product (host arithmetic, no launch): 0..3 = the
  * 8-phase configurations in the order above, 1000 + BM = the 16-wave kernel, -1 = unsupported shape.  Honours "gemm_config". */
@@ -439,7 +452,8 @@ int mmada_gemm_swiglu_bt(const void* A, const void* W, void* C, int M, int N, in
 /* RMSLayerNorm.forward (model/modeling_llada.py:301-329): out = w * bf16(x * rsqrt(mean(x²)+eps)). */
 int mmada_rmsnorm(const void* x, const void* w, void* out, int rows, int d, float eps, void* stream);
 /* Unmasked non-causal SDPA over [B,H,L,128] q/k/v (bf16, contiguous) → out [B,L,H*128]
- * (model/modeling_llada.py:643-679,731-744). Uses the handle's workspace for the K-major V copy. */
+ * (model/modeling_llada.py:643-679,731-744). Uses the handle's workspace for the padded q / k, the K-major V copy and the
+ * key-split scratch. */
 int mmada_sdpa(mmada_handle* h, const void* q, const void* k, const void* v, void* out, int B, int H, int Hkv, int L,
                void* stream);
 

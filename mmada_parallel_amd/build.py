@@ -1,19 +1,31 @@
 """Build libmmada_mi355x.so (the C-ABI of include/mmada_mi355x.h) for gfx950 with hipcc, in-tree.
 
 hipcc cross-compiles without a GPU; the resulting .so sits next to this file so it travels with the repo snapshot.
+Translation units are compiled in parallel (one hipcc per .hip, objects under csrc/_obj/) and linked once.
+
+`verify=True` (what __graft_entry__.build() passes) also checks the COMPILED code of the hand-scheduled kernels with
+tools/isa_check.py and fails the build on a violation: the LDS-DMA requests of gemm8.hip / attention.hip / attention64.hip are
+asm statements that write M0 themselves, which is only correct while hipcc keeps nothing live in M0 across them and while
+nothing but LDS-DMA sits in the vector-memory queue in front of a counted wait — properties of the compiler's output, not
+of the source, so a compiler upgrade must not be able to break them silently.
 """
 from __future__ import annotations
 
 import os
 import shutil
 import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_obj")
 LIB_NAME = "libmmada_mi355x.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
 SOURCES = ["gemm.hip", "gemm8.hip", "attention.hip", "attention64.hip", "elementwise.hip", "sampler.hip", "vq_decoder.hip", "graph.hip", "tp_comm.hip", "probe.hip", "api.hip"]
 HEADERS = ["common.h", "kernels.h", "gemm_epilogue.h", "handle.h", "attention.h", os.path.join("..", "..", "include", "mmada_mi355x.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 
 
 def _hipcc() -> str:
@@ -31,21 +43,68 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def _run(cmd):
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + proc.stdout + proc.stderr)
+    return proc.stdout
+
+
+def compile_objects(out_dir: str, extra_flags=(), force: bool = False, verbose: bool = False, jobs: int = 0):
+    """One object per translation unit, in parallel; only units older than their sources / headers are recompiled."""
+    os.makedirs(out_dir, exist_ok=True)
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    todo, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(out_dir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        sp = os.path.join(CSRC, src)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(sp)):
+            todo.append([_hipcc(), *FLAGS, *extra_flags, "-c", sp, "-o", obj])
+    if verbose:
+        for c in todo:
+            print(" ".join(c))
+    with ThreadPoolExecutor(max_workers=jobs or min(len(todo) or 1, os.cpu_count() or 4)) as ex:
+        list(ex.map(_run, todo))
+    return objs
+
+
+def verify_isa() -> None:
+    """tools/isa_check.py on freshly compiled device code: raises on any violation (see the module docstring)."""
+    tools = os.path.join(ROOT, "tools")
+    if not os.path.exists(os.path.join(tools, "isa_check.py")):
+        print("build: tools/isa_check.py not found, compiled-code checks skipped", file=sys.stderr)
+        return
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import isa_check
+
+    with ThreadPoolExecutor(max_workers=3) as ex:
+        asm8, asma, asm64 = ex.map(isa_check.device_asm, ["gemm8.hip", "attention.hip", "attention64.hip"])
+    errors = []
+    errors += isa_check.check_gemm8(asm8)[1]          # counted waits, M0 contract, no spill, 16-byte epilogue stores
+    errors += isa_check.check_attention(asma)[1]      # M0 contract, counted LDS waits, no spill
+    body64, _ = isa_check.kernels(asm64)
+    for name, lines in body64.items():
+        if "attn64_fwd_kernel" in name:
+            errors += isa_check.check_m0(name, lines)
+    if errors:
+        raise RuntimeError("compiled-code checks failed (tools/isa_check.py):\n" + "\n".join(errors))
+
+
+def build(force: bool = False, verbose: bool = False, verify: bool = False) -> str:
     """Compile every HIP translation unit for gfx950 into one shared library; returns its path."""
     if not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-result"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB_PATH + ".tmp"]
-    if verbose:
-        print(" ".join(cmd))
-    proc = subprocess.run(cmd, capture_output=True, text=True)
-    if proc.returncode != 0:
-        raise RuntimeError("hipcc failed:\n" + proc.stdout + proc.stderr)
+    with ThreadPoolExecutor(max_workers=2) as ex:
+        chk = ex.submit(verify_isa) if verify else None
+        objs = compile_objects(OBJ, force=force, verbose=verbose)
+        _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"])
+        if chk is not None:
+            chk.result()
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, verify="--verify" in sys.argv))

@@ -139,6 +139,9 @@ size_t mmada_workspace_bytes(const mmada_handle* h, int B, int L) {
 int mmada_set_workspace(mmada_handle* h, void* ws, size_t bytes) {
     if (!h || !ws) return mm_fail("mmada_set_workspace: null argument");
     if (((uintptr_t)ws) & 255) return mm_fail("mmada_set_workspace: workspace must be 256-byte aligned");
+    if (bytes < 65536) return mm_fail("mmada_set_workspace: %zu bytes is below the 64 KiB header", bytes);
+    // the first 64 KiB hold the arrival counters of the attention kernel's key split: zero when handed over, zero after every launch
+    MM_CHECK_HIP(hipMemset(ws, 0, 65536));
     h->ws = (char*)ws;
     h->ws_bytes = bytes;
     h->B = h->L = 0;
@@ -156,6 +159,7 @@ static int apply_carve(mmada_handle* h, int B, int L, hipStream_t s) {
     h->att = (bf16_t*)(h->ws + c.att); h->hbuf = (bf16_t*)(h->ws + c.h); h->q = (bf16_t*)(h->ws + c.q);
     h->k = (bf16_t*)(h->ws + c.k); h->vT = (bf16_t*)(h->ws + c.vT); h->xg = (bf16_t*)(h->ws + c.xg);
     h->rows_all = (int32_t*)(h->ws + c.rows);
+    h->attn_split = h->ws + c.split; h->attn_split_bytes = c.split_bytes;
     h->posmap = (int32_t*)(h->ws + c.posmap);
     // vT columns never written by the QKV epilogue (keys >= Lp; the key order inside a 16-key group is permuted, so
     // start at the last group boundary) are multiplied by P == 0: keep them finite
@@ -228,12 +232,12 @@ int mmada_attn_partial(mmada_handle* h, int layer, void* stream) {
         ProfScope p(h, layer, 1, 4.0 * h->hq_l * orows * (cc ? cc->L : h->L) * 128.0, s);
         if (cc) {  // compact (or all) queries of this call against the slot's keys / values of the whole sequence
             if (launch_attention(h->q, g.k, g.vT, h->att, h->B, h->hq_l, h->hkv_l, cc->L, h->Lp, cc->Lkv, h->Lp,
-                                 h->hq_l * 128, s, 0, h->Lkv)) return 1;
+                                 h->hq_l * 128, s, 0, h->Lkv, h->attn_split, h->attn_split_bytes)) return 1;
         } else if (W) {
             if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, wend, h->Lkv, W,
-                                 h->hq_l * 128, s, wbeg)) return 1;
+                                 h->hq_l * 128, s, wbeg, 0, h->attn_split, h->attn_split_bytes)) return 1;
         } else if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->Lp, h->Lkv, h->Lp,
-                                    h->hq_l * 128, s)) return 1;
+                                    h->hq_l * 128, s, 0, 0, h->attn_split, h->attn_split_bytes)) return 1;
     }
     GemmArgs o{};
     o.A = h->att; o.W = lw.wo; o.C = h->y;
@@ -307,8 +311,12 @@ int mmada_set_option(const char* name, int value) {
     if (!strcmp(name, "gemm_config")) { gemm_force_config(value); return 0; }
     if (!strcmp(name, "gemm_silu_lut")) { gemm_set_silu_lut(value); return 0; }
     if (!strcmp(name, "gemm_short_tiles")) { gemm8_set_short_tiles(value); return 0; }
+    if (!strcmp(name, "gemm_tile_order")) { gemm8_set_tile_order(value); return 0; }
     if (!strcmp(name, "attention_form")) { attention_force_form(value); return 0; }
+    if (!strcmp(name, "attention_split")) { attention_set_split(value); return 0; }
+    if (!strcmp(name, "attention_skip_idle")) { attention_set_skip_idle(value); return 0; }
     if (!strcmp(name, "probe_variant")) { mfma_probe_set_variant(value); return 0; }
+    if (!strcmp(name, "tp_allow_single_rank")) { tp_allow_single_rank(value); return 0; }
     return mm_fail("mmada_set_option: unknown option '%s'", name);
 }
 
@@ -339,7 +347,7 @@ size_t mmada_stream_bytes(const mmada_handle* h) { return h ? (size_t)h->Mcur * 
 
 int mmada_forward_body(mmada_handle* h, const int64_t* ids, int B, int L, void* stream) {
     if (!h) return mm_fail("mmada_forward_body: null handle");
-    if (h->cfg.tp_size != 1) {
+    if (h->cfg.tp_size != 1 || tp_comm_connected(h)) {   // (a connected one-rank group: the tp_allow_single_rank test switch)
         // tensor parallel: the exchange step lives in the library (tp_comm.hip); the residual stream stays sharded by rows
         if (!h->tp)
             return mm_fail("mmada_forward_body: tp_size=%d needs a connected collective (mmada_comm_create + "
@@ -624,15 +632,16 @@ int mmada_sdpa(mmada_handle* h, const void* q, const void* k, const void* v, voi
     hipStream_t s = (hipStream_t)stream;
     const int Lkv = ceil_to(L, 64);
     const size_t qb = align_up((size_t)B * H * Lkv * 128 * 2, 256), kb = align_up((size_t)B * Hkv * Lkv * 128 * 2, 256);
-    if (!h->ws || qb + 2 * kb > h->ws_bytes) return mm_fail("mmada_sdpa: workspace too small (%zu needed)", qb + 2 * kb);
-    bf16_t* qp = (bf16_t*)h->ws;
-    bf16_t* kp = (bf16_t*)(h->ws + qb);
-    bf16_t* vt = (bf16_t*)(h->ws + qb + kb);
+    const size_t sb = align_up(attention_split_bytes(B, H, L), 256);   // key-split scratch first: its counters are the workspace's first 64 KiB
+    if (!h->ws || sb + qb + 2 * kb > h->ws_bytes) return mm_fail("mmada_sdpa: workspace too small (%zu needed)", sb + qb + 2 * kb);
+    bf16_t* qp = (bf16_t*)(h->ws + sb);
+    bf16_t* kp = (bf16_t*)(h->ws + sb + qb);
+    bf16_t* vt = (bf16_t*)(h->ws + sb + qb + kb);
     h->M = 0;  // the resident forward (if any) is clobbered
     if (launch_pad_heads((const bf16_t*)q, qp, B * H, L, Lkv, s)) return 1;
     if (launch_pad_heads((const bf16_t*)k, kp, B * Hkv, L, Lkv, s)) return 1;
     if (launch_transpose_v((const bf16_t*)v, vt, B * Hkv, L, Lkv, s)) return 1;
-    return launch_attention(qp, kp, vt, (bf16_t*)out, B, H, Hkv, L, L, Lkv, L, H * 128, s);
+    return launch_attention(qp, kp, vt, (bf16_t*)out, B, H, Hkv, L, L, Lkv, L, H * 128, s, 0, 0, h->ws, sb);
 }
 
 }  // extern "C"

@@ -611,9 +611,9 @@ double plan_makespan(int pairs, int F, int H, int cus) {
 // full passes per (batch, head) pair for `pairs` pairs of nqb q-blocks on `cus` CUs (cached: a handful of shapes per run)
 int plan_full_passes(int pairs, int nqb, int cus) {
     static std::mutex mu;
-    static std::map<std::pair<int, int>, int> cache;
+    static std::map<std::pair<long long, int>, int> cache;
     std::lock_guard<std::mutex> lock(mu);
-    const auto key = std::make_pair(pairs, nqb);
+    const auto key = std::make_pair((long long)pairs * 4096 + cus, nqb);   // the plan depends on the device's CU count too
     const auto it = cache.find(key);
     if (it != cache.end()) return it->second;
     int bestF = 0;
@@ -652,11 +652,17 @@ int launch_attention64(attn_detail::AttnArgs a, int B, hipStream_t s, int var) {
 #else
     if (var != 0) return mm_fail("attention64: diagnostic variant %d exists in -DMMADA_TUNE builds only", var);
 #endif
-    static int cus = 0;
+    // 64 KiB of dynamic LDS: above the default limit, per device like every other launcher's attribute
+    static MmOncePerDevice attr_set;
+    MM_ONCE_PER_DEVICE(attr_set, MM_CHECK_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILE_BYTES)));
+    static std::atomic<int> cus_of[16];
+    const int slot = mm_device_slot();
+    int cus = slot >= 0 ? cus_of[slot].load(std::memory_order_relaxed) : 0;
     if (!cus) {
         int dev = 0;
         MM_CHECK_HIP(hipGetDevice(&dev));
         MM_CHECK_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (slot >= 0) cus_of[slot].store(cus, std::memory_order_relaxed);
     }
     const int pairs = a.Hq * B;
     const int nqb = (a.Lq_rows - a.q_begin + 31) / 32;

@@ -22,6 +22,9 @@
 // anything else touches it.
 #include <cstdlib>
 
+#include <atomic>
+#include <mutex>
+
 #include "gemm_epilogue.h"
 
 namespace {
@@ -288,30 +291,44 @@ __global__ void silu_lut_kernel(uint16_t* t) {
     }
     t[idx] = v;
 }
-static int g_silu_lut = -1;  // -1: read MMADA_GEMM_SILU_LUT once (default on)
+static std::atomic<int> g_silu_lut{-1};  // -1: read MMADA_GEMM_SILU_LUT once (default on)
 static int silu_lut_for_device(const uint16_t** out, hipStream_t s) {
-    static uint16_t* lut[16] = {};
+    static std::atomic<uint16_t*> lut[16];
+    static std::mutex mu;
     *out = nullptr;
-    if (g_silu_lut < 0) {
+    if (g_silu_lut.load(std::memory_order_relaxed) < 0) {
         const char* e = getenv("MMADA_GEMM_SILU_LUT");
-        g_silu_lut = e && e[0] == '0' ? 0 : 1;
+        g_silu_lut.store(e && e[0] == '0' ? 0 : 1, std::memory_order_relaxed);
     }
-    if (!g_silu_lut) return 0;
+    if (!g_silu_lut.load(std::memory_order_relaxed)) return 0;
     int dev = 0;
     MM_CHECK_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16) return 0;
-    if (!lut[dev]) {   // first SwiGLU launch on this device (eager: a hipMalloc cannot be captured, like the zero rows below)
-        uint16_t* p = nullptr;
-        MM_CHECK_HIP(hipMalloc(&p, gemm_detail::SiluLut::BYTES));
-        hipLaunchKernelGGL(silu_lut_kernel, dim3((gemm_detail::SiluLut::ENTRIES + 255) / 256), dim3(256), 0, s, p);   // ordered before the GEMM
-        MM_CHECK_HIP(hipGetLastError());
-        MM_CHECK_HIP(hipStreamSynchronize(s));   // once per device: another stream's first SwiGLU launch must not overtake the fill
-        lut[dev] = p;
+    uint16_t* have = lut[dev].load(std::memory_order_acquire);
+    if (!have) {   // first SwiGLU launch on this device: allocate and fill once (two host threads: one does it, the other waits)
+        // A hipMalloc + synchronise cannot run under hipGraph capture (e.g. the option switched on after the eager warm-up
+        // step): that launch evaluates SiLU instead — the same bits — and a later eager launch builds the table.
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+            (void)hipGetLastError();
+            return 0;
+        }
+        std::lock_guard<std::mutex> lock(mu);
+        have = lut[dev].load(std::memory_order_acquire);
+        if (!have) {
+            uint16_t* p = nullptr;
+            MM_CHECK_HIP(hipMalloc(&p, gemm_detail::SiluLut::BYTES));
+            hipLaunchKernelGGL(silu_lut_kernel, dim3((gemm_detail::SiluLut::ENTRIES + 255) / 256), dim3(256), 0, s, p);   // ordered before the GEMM
+            MM_CHECK_HIP(hipGetLastError());
+            MM_CHECK_HIP(hipStreamSynchronize(s));   // once per device: another stream's first SwiGLU launch must not overtake the fill
+            lut[dev].store(p, std::memory_order_release);
+            have = p;
+        }
     }
-    *out = lut[dev];
+    *out = have;
     return 0;
 }
-void gemm_set_silu_lut(int on) { g_silu_lut = on != 0 ? 1 : 0; }
+void gemm_set_silu_lut(int on) { g_silu_lut.store(on != 0 ? 1 : 0, std::memory_order_relaxed); }
 
 int launch_gemm(int epi, const GemmArgs& g_in, hipStream_t s) {
     GemmArgs g = g_in;

@@ -363,12 +363,14 @@ bool short_tiles_on() {
     return g_short_tiles != 0;
 }
 
+int g_tile_order = -1;  // -1: read MMADA_GEMM_TILE_ORDER once; 0: default; GM * 100 + GN
+
 template <int EPI, class G>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ntm = (g.M + G::BM - 1) / G::BM, ntn = (g.N + G::BN - 1) / G::BN;
     int mt, nt;
-    tile_coords<1024 / G::BN>(xcd_remap(blockIdx.x, gridDim.x), ntm, ntn, mt, nt);
+    tile_coords_g(xcd_remap(blockIdx.x, gridDim.x), ntm, ntn, g.tile_gm, g.tile_gn, mt, nt);
     // short row tiles (Gemm8::CAN_DROP): pitch 304, every row tile but the last one ends 16 rows early
     const bool short_tiles = G::CAN_DROP && g.row_drop != 0;
     const bool short_tile = short_tiles && mt < ntm - 1;
@@ -426,6 +428,12 @@ int launch_cfg8(const GemmArgs& g, hipStream_t s) {
     // short row tiles when ntm - 1 tiles of 304 rows and one of <= 320 cover M (same tile count, 5 % fewer MFMAs in all
     // but the last row tile): M = 2440 -> 7 x 304 + 312, M = 4880 -> 15 x 304 + 320
     ga.row_drop = G::CAN_DROP && short_tiles_on() && ntm >= 2 && (ntm - 1) * G::SHORT_BM + G::BM >= g.M ? 1 : 0;
+    if (g_tile_order < 0) {
+        const char* e = getenv("MMADA_GEMM_TILE_ORDER");
+        g_tile_order = e ? atoi(e) : 0;
+    }
+    ga.tile_gm = g_tile_order > 0 ? g_tile_order / 100 : 0;
+    ga.tile_gn = g_tile_order > 0 && g_tile_order % 100 > 0 ? g_tile_order % 100 : 1024 / G::BN;
     hipLaunchKernelGGL(fn, dim3(ntm * ntn), dim3(512), LDS_BYTES, s, ga);
     MM_CHECK_HIP(hipGetLastError());
     return 0;
@@ -470,6 +478,7 @@ bool gemm8_supports(const GemmArgs& g) {
 }
 
 void gemm8_set_short_tiles(int on) { g_short_tiles = on != 0 ? 1 : 0; }
+void gemm8_set_tile_order(int code) { g_tile_order = code < 0 ? -1 : code; }
 
 int launch_gemm8(int epi, int cfg, const GemmArgs& g, hipStream_t s) {
     if (!gemm8_supports(g)) return mm_fail("gemm8: unsupported shape M=%d N=%d K=%d", g.M, g.N, g.K);

@@ -49,16 +49,28 @@ typedef __attribute__((address_space(3))) const uint16_t* lds_u16_ptr;
 MM_DEVICE uint32_t lds_u16(int byte_off) { return *(lds_u16_ptr)(uint32_t)byte_off; }   // LDS addresses are plain integers here (gemm8.hip)
 #pragma clang diagnostic pop
 
-// Tile sequence number -> (row tile, column tile): grouped order, GN column tiles (1024 columns) x all row tiles per group, so
-// workgroups with neighbouring sequence numbers (same XCD after xcd_remap) share A and W panels in their L2.
-template <int GN = 4>
-MM_DEVICE void tile_coords(int t, int ntm, int ntn, int& mt, int& nt) {
-    const int gsize = GN * ntm;
-    const int grp = t / gsize, rem = t - grp * gsize;
-    const int gn = min(GN, ntn - grp * GN);
-    mt = rem / gn;
-    nt = grp * GN + (rem - mt * gn);
+// Tile sequence number -> (row tile, column tile): grouped order.  The sequence is cut into column BANDS of GN column tiles; inside
+// a band into GROUPS of GM row tiles x GN column tiles (GM <= 0 or >= ntm: the whole band), column tile fastest.  Workgroups with
+// neighbouring sequence numbers run on one XCD at the same time (xcd_remap), so a group is what shares A and W panels in that
+// XCD's L2: per XCD-round of 32 tiles the fabric delivers gm A panels + gn W panels (gm * gn = 32).  Default GM = all rows,
+// GN = 1024 / BN; mmada_set_option("gemm_tile_order", ...) picks other shapes for the FETCH_SIZE sweep.
+MM_DEVICE void tile_coords_g(int t, int ntm, int ntn, int GM, int GN, int& mt, int& nt) {
+    const int band = GN * ntm;
+    const int b = t / band, rem = t - b * band;
+    const int gn = min(GN, ntn - b * GN);
+    if (GM <= 0 || GM >= ntm) {
+        mt = rem / gn;
+        nt = b * GN + (rem - mt * gn);
+        return;
+    }
+    const int gsz = GM * gn;
+    const int rg = rem / gsz, rr = rem - rg * gsz;
+    const int r = rr / gn;
+    mt = rg * GM + r;
+    nt = b * GN + (rr - r * gn);
 }
+template <int GN = 4>
+MM_DEVICE void tile_coords(int t, int ntm, int ntn, int& mt, int& nt) { tile_coords_g(t, ntm, ntn, 0, GN, mt, nt); }
 
 // m_lim: first row this tile does NOT write (g.M, or the end of a short row tile of gemm8.hip).
 // Wave grid WM x WN over the block tile, a wave owns TM x TN outputs = FM x FN fragments of 16 x 16:
@@ -384,5 +396,8 @@ void gemm_force_config(int code);
 int gemm_plan_code(int M, int N, int K);  // the planner's pick for a plain product: 0..3 or 1000 + BM; -1: unsupported shape
 // short row tiles of the 320-row configurations (gemm8.hip) on / off; on by default
 void gemm8_set_short_tiles(int on);
+// tile order of the 8-phase kernel: 0 / -1 = default (bands of 1024 columns, all row tiles per group); GM * 100 + GN = groups of
+// GM row tiles x GN column tiles (sweeps: tools/gemm_sweep.py --order)
+void gemm8_set_tile_order(int code);
 // SiLU table of the SwiGLU epilogue (8-phase kernel) on / off; on by default
 void gemm_set_silu_lut(int on);

@@ -49,6 +49,8 @@ struct mmada_handle {
     bf16_t *x = nullptr, *y = nullptr, *xn = nullptr, *att = nullptr, *hbuf = nullptr, *q = nullptr, *k = nullptr,
            *vT = nullptr, *xg = nullptr;
     int32_t* rows_all = nullptr;
+    void* attn_split = nullptr;   // key-split scratch of the attention kernel (counters at workspace offset 0) and its size
+    size_t attn_split_bytes = 0;
     int32_t* posmap = nullptr;  // [B*Lp] sequence position of every compact stream row (compute-mask forward)
     // dLLM cache: slots, and the one a forward in flight writes its keys / values into (cc != null only inside
     // mmada_forward_cached); cc_pos: position map of a compute-mask step (null: every row is computed)
@@ -76,6 +78,8 @@ struct mmada_handle {
 int tp_forward_body(mmada_handle* h, hipStream_t s);              // all blocks of a tensor-parallel forward, after mmada_embed
 int tp_gather_stream(mmada_handle* h, bf16_t* full_out, hipStream_t s);  // residual stream rows of every owner -> [M, d]
 void tp_comm_free(mmada_handle* h);
+void tp_allow_single_rank(int on);   // test switch: mmada_comm_create accepts tp_size == 1
+bool tp_comm_connected(const mmada_handle* h);   // a transport (or the no-exchange diagnostic) is active on this handle
 int tp_head_gather(mmada_handle* h, const int32_t* rows, int R, hipStream_t s);  // xg[r] = xn[row r] (xn already = ln_f(x))
 
 struct ProfScope {
@@ -107,7 +111,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static inline int ceil_to(int v, int a) { return (v + a - 1) / a * a; }
 
 struct Carve {
-    size_t x, y, xn, att, h, q, k, vT, xg, rows, posmap, total;
+    size_t split, split_bytes, x, y, xn, att, h, q, k, vT, xg, rows, posmap, total;
     int Lp, Lkv, M;
 };
 
@@ -123,6 +127,11 @@ static Carve carve_for(const mmada_handle* h, int B, int L) {
         off = align_up(off + bytes, 256);
         return o;
     };
+    // scratch of the attention kernel's key split (attention.h): FIRST, so that its counters sit at workspace offset 0 whatever
+    // the shape — mmada_set_workspace zeroes them once, every launch leaves them zero
+    c.split = 0;
+    c.split_bytes = attention_split_bytes(B, h->hq_l, L);
+    take(c.split_bytes);
     // tensor parallel: a row chunk is split into tp equal owner slices of a multiple of 8 rows; the last chunk's slices
     // may reach past M (equal counts for the RCCL reduce-scatter / all-gather), so the stream buffers carry pad rows
     const size_t mrows = (size_t)c.M + (h->cfg.tp_size > 1 ? 8 * h->cfg.tp_size : 0);

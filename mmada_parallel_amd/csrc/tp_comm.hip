@@ -32,6 +32,9 @@
 
 #include "handle.h"
 
+int g_allow_single_rank = 0;   // mmada_set_option("tp_allow_single_rank", 1): test switch, see mmada_comm_create
+void tp_allow_single_rank(int on) { g_allow_single_rank = on != 0; }
+
 namespace {
 
 constexpr int TP_MAX = 8;
@@ -472,7 +475,7 @@ int tp_forward_body(mmada_handle* h, hipStream_t s) {
         {   // ---- attention over this rank's heads: the one join point (every key of a sequence) ----
             ProfScope p(h, layer, 1, 4.0 * h->hq_l * (double)h->B * h->L * h->L * 128.0, s);
             if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->Lp, h->Lkv, h->Lp,
-                                 h->hq_l * 128, s)) return 1;
+                                 h->hq_l * 128, s, 0, 0, h->attn_split, h->attn_split_bytes)) return 1;
         }
         // ---- attn_out (row-parallel) chunk by chunk; chunk k's exchange runs under chunk k+1's GEMM ----
         for (int k = 0; k < nch; ++k) {
@@ -543,6 +546,8 @@ int tp_gather_stream(mmada_handle* h, bf16_t* full_out, hipStream_t s) {
     return 0;
 }
 
+bool tp_comm_connected(const mmada_handle* h) { return h->tp && h->tp->mode != 0; }
+
 void tp_comm_free(mmada_handle* h) {
     TpComm* c = h->tp;
     if (!c) return;
@@ -567,7 +572,11 @@ int mmada_comm_export_bytes(void) { return (int)sizeof(CommExport); }
 
 int mmada_comm_create(mmada_handle* h, int max_rows, void* export_out) {
     if (!h || max_rows <= 0) return mm_fail("mmada_comm_create: bad argument");
-    if (h->cfg.tp_size < 2 || h->cfg.tp_size > TP_MAX) return mm_fail("mmada_comm_create: tp_size must be 2..%d", TP_MAX);
+    // tp_size == 1 behind mmada_set_option("tp_allow_single_rank", 1): a one-rank group runs EVERY line of the exchange (RCCL
+    // reduce-scatter / all-gather of one rank are copies, the pull transport has no peer to wait for) and must reproduce the
+    // plain forward bit for bit — the test that executes the RCCL transport without a second GPU (tests/test_gpu_tp.py)
+    if ((h->cfg.tp_size < 2 && !(h->cfg.tp_size == 1 && g_allow_single_rank)) || h->cfg.tp_size > TP_MAX)
+        return mm_fail("mmada_comm_create: tp_size must be 2..%d", TP_MAX);
     if (h->tp) tp_comm_free(h);
     TpComm* c = new TpComm();
     c->rank = h->cfg.tp_rank; c->size = h->cfg.tp_size; c->d = h->cfg.d_model;
@@ -708,7 +717,9 @@ int mmada_comm_set_timeout(mmada_handle* h, double seconds) {
     return 0;
 }
 
-/* mode: 0 none, 1 pull (IPC / same-process peers), 2 RCCL.  err: != 0 after a hand-off timed out (synchronises `stream`). */
+/* mode: 0 none, 1 pull (IPC / same-process peers), 2 RCCL, 3 the "no exchange" DIAGNOSTIC (the forward's values are void: callers
+ * that report results must treat 3 as an error — check_tp_exchange does).  err: != 0 after a hand-off timed out (synchronises
+ * `stream`). */
 int mmada_comm_status(mmada_handle* h, int* mode_out, int* err_out, int* finegrained_out, void* stream) {
     if (!h) return mm_fail("mmada_comm_status: null handle");
     if (mode_out) *mode_out = h->tp ? h->tp->mode : 0;
@@ -727,7 +738,7 @@ int mmada_comm_status(mmada_handle* h, int* mode_out, int* err_out, int* finegra
 int mmada_comm_set_mode(mmada_handle* h, int mode) {
     if (!h || !h->tp) return mm_fail("mmada_comm_set_mode: no comm");
     TpComm* c = h->tp;
-    const int other = c->rank == 0 ? 1 : 0;
+    const int other = c->size == 1 ? 0 : (c->rank == 0 ? 1 : 0);
     if (mode == 1 && !c->peers.ctr[other]) return mm_fail("mmada_comm_set_mode: the pull transport was never connected");
     if (mode == 2 && !c->comm) return mm_fail("mmada_comm_set_mode: the RCCL transport was never connected");
     if (mode == 3 && c->mode == 0) return mm_fail("mmada_comm_set_mode: connect a transport before the no-exchange diagnostic");

@@ -71,6 +71,9 @@ def check_tp_exchange(model):
     (the read-out of the final ids): raises instead of returning an image computed from stale partial sums."""
     if getattr(model, "_comm_in_library", False) and hasattr(model, "comm_status"):
         st = model.comm_status()
+        if st["mode"] == "no-exchange diagnostic":
+            raise abi.MmadaError("tensor-parallel exchange: the no-exchange diagnostic (mmada_comm_set_mode 3) is still on; "
+                                 "the generated tokens are void")
         if st["error"]:
             raise abi.MmadaError(f"tensor-parallel exchange: hand-off timed out waiting for rank {st['error'] - 1} "
                                  f"(transport {st['mode']}); the generated tokens are void")

@@ -386,7 +386,7 @@ class LLaDAForMultiModalGeneration:
         mode, err, fine = C.c_int(), C.c_int(), C.c_int()
         abi.check(self._lib.mmada_comm_status(self._handle, C.byref(mode), C.byref(err), C.byref(fine), abi.stream_ptr()),
                   "mmada_comm_status")
-        return {"mode": {0: "none", 1: "pull", 2: "rccl"}[mode.value], "error": err.value, "finegrained_counters": bool(fine.value & 1),
+        return {"mode": {0: "none", 1: "pull", 2: "rccl", 3: "no-exchange diagnostic"}[mode.value], "error": err.value, "finegrained_counters": bool(fine.value & 1),
                 "finegrained_buffers": bool(fine.value & 2)}
 
     def comm_selftest(self, iters: int = 3, L: int = 96) -> bool:

@@ -142,6 +142,32 @@ def peaked_delta(job: dict) -> int:
     return job["image_start"] - 40
 
 
+# ---- the M variant's free-running job on a peaked checkpoint (BASELINE configs[3] geometry) --------------------------------
+M_PEAKED_KW = dict(text_cfg=2.5, image_cfg=4.0, text_steps=24, image_steps=8, image_temperature=1.0, text_temperature=0.0)
+M_PEAKED_BETA = 2.0   # LM-head gain of the planted circuit: the text CFG combine multiplies logit margins by up to 2.5 and the
+                      # image combine by 5, so the gain is lower than the A recipe's 5 (keeps fp64 text confidences below 1.0:
+                      # no exact ties for the reference's torch.topk to order)
+
+
+def m_peaked_job(seed: int = 7) -> dict:
+    """MMaDA-Parallel-M interleave_generate inputs at the bench's configs[3] geometry (MMaDA-Parallel-M/inference.py:79,
+    113-127 with stand-in special ids): prompt = <|interleave|> <|soi|> 1024 image codes <|eoi|> 40 text tokens (P = 1067);
+    the sampler appends <|soi|> 1024 x MASK <|eoi|> <bos> 255 x MASK: L = 2349.  The unconditional prompt has token 0 in place
+    of the image codes and other text (as tools/m_end_to_end.py / bench.py --config 3 build it).  delta = 1066: every masked
+    output-image position copies the input-image code at the same raster position."""
+    g = torch.Generator().manual_seed(seed)
+    N, T, n_text = 1024, 256, 40
+    img = torch.randint(0, CODEBOOK, (N,), generator=g) + TEXT_VOCAB
+    text = torch.randint(0, 100000, (n_text,), generator=g)
+    un_text = torch.randint(0, 100000, (n_text,), generator=g)
+    head, eoi = torch.tensor([126340, 126084]), torch.tensor([126085])
+    inp = torch.cat([head, img, eoi, text])
+    unc = torch.cat([head, torch.zeros_like(img), eoi, un_text])
+    P = int(inp.shape[0])
+    return dict(input_ids=inp, uncond_input_ids=unc, N=N, T=T, P=P, L=P + 1 + N + 1 + T, delta=P - 1, soi=126084, eoi=126085,
+                bos=126080, text_vocab=TEXT_VOCAB, codebook=CODEBOOK, img_start=P + 1, text_start=P + 1 + N + 1)
+
+
 def host_isa() -> str:
     """Which bf16 GEMM code path this host's CPU gives torch / oneDNN: the reference's CPU forward (and therefore every
     float fixture recorded from it) is bit-reproducible only within one class.  Fixtures that contain float

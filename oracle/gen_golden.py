@@ -25,6 +25,9 @@ once per class, <name>.<synth.host_isa()>.npz; this script writes the file of th
   peaked_traj.*.npz  generate_ti2ti free-running on the PEAKED synthetic checkpoint (synth.synthetic_state_dict_peaked, 4 blocks,
                      d = 1024) at BASELINE configs[0] geometry (L = 1654, 32 text + 16 image steps, 64 model calls): ids of every
                      call + outputs — the trajectory a re-ordered GEMM can be held to (decision margins >> bf16 noise)
+  m_peaked_traj.*.npz  MMaDA-Parallel-M: MMadaModelLM.interleave_generate free-running on the M tree's own LLaDAModelLM with the
+                     peaked checkpoint at configs[3] geometry (L = 2349, batch-2 forwards, text_cfg 2.5, image_cfg 4): ids of every
+                     call + outputs — models/modeling_mmada.py:117-248, models/modeling_llada.py
   dllm_cache.*.npz   LLaDAModelLM.forward(use_cache=True, to_compute_mask=..., cat=...) on the tiny model: a prime call and
                      compute-mask steps on changed ids, two cache keys, with and without caching(True): logit slices +
                      arg-max of the returned logit cache — model/modeling_llada.py:593-600,929-940,1244-1245,1406-1426
@@ -455,6 +458,110 @@ def gen_dllm_cache():
     print(f"dllm_cache.{synth.host_isa()}: {len(d) // 3} calls")
 
 
+# ---- M variant end to end: the reference's interleave_generate on the reference's own LLaDAModelLM (peaked checkpoint) ----
+def _import_m_models():
+    """MMaDA-Parallel-M/models as a package WITHOUT its __init__ (which imports files that do not exist, SURVEY 2.1 #16)."""
+    import importlib
+    import types
+
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [M_REF + "/models"]
+    saved = sys.modules.get("models")
+    sys.modules["models"] = pkg
+    return importlib.import_module("models.modeling_mmada"), importlib.import_module("models.modeling_llada"), \
+        importlib.import_module("models.configuration_llada"), saved
+
+
+def compute_m_peaked() -> dict:
+    """The UNMODIFIED MMaDA-Parallel-M sampler (MMadaModelLM.interleave_generate, models/modeling_mmada.py:117-248) free-running
+    on the UNMODIFIED M denoiser (models/modeling_llada.py LLaDAModelLM, 4 blocks, d = 1024, bf16, CPU) with the peaked
+    synthetic checkpoint at BASELINE configs[3] geometry: L = 2349, batch 2 (cond || uncond) every step, text_cfg 2.5,
+    image_cfg 4, 24 text steps of which 8 are image steps.  torch.multinomial / Tensor.uniform_ are served by per-call seeded
+    generators (SeededRng) that the oracle and the GPU test replay.  Records the ids of every model call and the outputs, and
+    per call the largest fp64 text confidence among the still-masked rows (1 - p must stay > 0: no exact ties for topk)."""
+    from unittest import mock
+
+    from oracle.interleave_oracle import SeededRng
+
+    mm, ml, mc, saved = _import_m_models()
+    try:
+        cfg, job, kw = synth.CFG_PEAKED, synth.m_peaked_job(), dict(synth.M_PEAKED_KW)
+        sd = synth.synthetic_state_dict_peaked(cfg, job["delta"], beta=synth.M_PEAKED_BETA)
+        full = dict(synth.full_config(cfg), mask_token_id=synth.MASK)
+        with contextlib.redirect_stdout(io.StringIO()):
+            model = ml.LLaDAModelLM(mc.LLaDAConfig(**full))
+        # environment shim, not a change of the reference: LLaDAConfig hands use_cache=False to PretrainedConfig.__init__, which
+        # the pinned transformers 4.46.2 stores as config.use_cache (forward reads it, models/modeling_llada.py:1407-1408) and
+        # the transformers 5.x of this container drops
+        model.config.use_cache = False
+        model.load_state_dict(sd, strict=True)
+        model = model.to(torch.bfloat16).eval()
+        calls, top_conf = [], []
+        ts = job["text_start"]
+
+        class Self:   # what interleave_generate touches of `self`: __call__ and config.mask_token_id
+            config = SimpleNamespace(mask_token_id=synth.MASK)
+
+            def __call__(self, ids):
+                calls.append(ids.clone())
+                with torch.no_grad():
+                    out = model(ids)
+                lg = out.logits
+                c, u = lg[0:1, ts:], lg[1:2, ts:]
+                comb = c + kw["text_cfg"] * (u - c)
+                masked = ids[0, ts:] == synth.MASK
+                if bool(masked.any()):
+                    p = torch.softmax(comb[0][masked].to(torch.float64), -1).max(-1).values
+                    top_conf.append(float((1.0 - p).min()))
+                else:
+                    top_conf.append(1.0)
+                return out
+
+        class Tok:
+            bos_token_id = job["bos"]
+
+            def __len__(self):
+                return job["text_vocab"]
+
+        cfgobj = SimpleNamespace(model=SimpleNamespace(mmada=SimpleNamespace(num_vq_tokens=job["N"], codebook_size=job["codebook"])),
+                                 dataset=SimpleNamespace(preprocessing=SimpleNamespace(max_seq_length=job["T"])))
+        rng = SeededRng(M_PEAKED_SEED)
+        real_uniform = torch.Tensor.uniform_
+
+        def fake_multinomial(inp_, num, replacement=False, *, generator=None):
+            return rng.multinomial(inp_)[:, None]
+
+        def fake_uniform(self, a=0, b=1, *, generator=None):
+            return real_uniform(self, a, b, generator=rng._g())
+
+        with mock.patch.object(torch, "multinomial", fake_multinomial), \
+                mock.patch.object(torch.Tensor, "uniform_", fake_uniform), \
+                contextlib.redirect_stdout(io.StringIO()):
+            img, text = mm.MMadaModelLM.interleave_generate(
+                Self(), job["input_ids"], job["uncond_input_ids"], reserved_token_mapping={"<|soi|>": job["soi"], "<|eoi|>": job["eoi"]},
+                config=cfgobj, uni_prompting=SimpleNamespace(text_tokenizer=Tok()), generator=None, **kw)
+        return dict(calls=torch.stack(calls, 0).numpy().astype(np.int32), img=img.numpy().astype(np.int64),
+                    text=text.numpy().astype(np.int64), one_minus_top_text_conf=np.array(top_conf, np.float64))
+    finally:
+        if saved is None:
+            sys.modules.pop("models", None)
+        else:
+            sys.modules["models"] = saved
+        for k in [k for k in sys.modules if k.startswith("models.")]:
+            sys.modules.pop(k, None)
+
+
+M_PEAKED_SEED = 53
+
+
+def gen_m_peaked():
+    d = compute_m_peaked()
+    np.savez_compressed(os.path.join(OUT, f"m_peaked_traj.{synth.host_isa()}.npz"), **d)
+    print(f"m_peaked_traj.{synth.host_isa()}: {d['calls'].shape[0]} batch-2 forwards of L = {d['calls'].shape[2]}; "
+          f"{len(set(d['img'].reshape(-1).tolist()))} distinct image ids, {len(set(d['text'].reshape(-1).tolist()))} distinct text ids; "
+          f"smallest 1 - p of a masked text row over all calls {d['one_minus_top_text_conf'].min():.3e}")
+
+
 # ---- M variant: MMadaModelLM.interleave_generate driven by stub logits and per-call seeded RNG draws ------------------
 M_REF = "/root/reference/MMaDA-Parallel-M"
 M_CASES = {
@@ -842,4 +949,5 @@ if __name__ == "__main__":
     gen_forward()
     gen_e2e()
     gen_peaked()
+    gen_m_peaked()
     gen_dllm_cache()

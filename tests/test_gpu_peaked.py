@@ -109,63 +109,178 @@ def test_peaked_free_running_trajectory_equals_the_reference_recording():
     assert rep["distinct_vq"] > 100 and rep["distinct_text"] > 100, "the planted circuit must give position-dependent predictions"
 
 
-@pytest.mark.parametrize("seed", [1])
-def test_peaked_post_cfg_decisions_at_8b_depth(seed):
-    """One image step of configs[1] (L = 2438, N = 1024) on a PEAKED 32-block, d = 4096 checkpoint: conditional and
-    unconditional forwards, c + 4 (c - u_img) in the reference's bf16 order, arg-max.  HIP vs the CPU oracle (the
-    reference's arithmetic) vs the same weights evaluated in fp32."""
+@pytest.fixture(scope="module")
+def peaked8b():
+    """ONE peaked 32-block, d = 4096 checkpoint (the A job's copy distance) shared by the three full-depth decision tests, with
+    the three evaluations of every branch cached: HIP, the CPU oracle (the reference's bf16 arithmetic) and the same weights in
+    fp32 (exact arithmetic on bf16-representable weights)."""
     from mmada_parallel_amd import LLaDAForMultiModalGeneration
     from oracle import llada_oracle
 
     cfg = dict(synth.CFG_8B)
-    job = synth.synthetic_job(512, 512, text_gen_length=256, prompt_len=64, uncond_prompt_len=24, seed=seed)
+    job = synth.synthetic_job(512, 512, text_gen_length=256, prompt_len=64, uncond_prompt_len=24, seed=1)
+    sd_dev = synth.synthetic_state_dict_peaked(cfg, synth.peaked_delta(job), device=DEV)
+    model = LLaDAForMultiModalGeneration.from_state_dict(synth.full_config(cfg), sd_dev, device=DEV, max_batch=2)
+    sd = {k: v.cpu() for k, v in sd_dev.items()}
+    del sd_dev
+    torch.cuda.empty_cache()
+    torch.set_num_threads(min(32, torch.get_num_threads()))
+    state = {"sd32": None}
+
+    def oracle_rows(x, rows_by_seq, lo, hi, fp32=False):
+        """[len(x)] lists of logits [rows, hi - lo] of the oracle forward (bf16 weights, or their fp32 copies)."""
+        if fp32 and state["sd32"] is None:
+            state["sd32"] = {k: v.float() for k, v in sd.items()}
+        sdd = state["sd32"] if fp32 else sd
+        h = llada_oracle.forward_hidden(sdd, cfg, x)
+        return [llada_oracle.head(sdd, cfg, h[b:b + 1, rows_by_seq], lo, hi)[0].float() for b in range(x.shape[0])]
+
+    return dict(cfg=cfg, job=job, model=model, oracle_rows=oracle_rows, cache={})
+
+
+def _a_branches(p8):
+    """Consumed image logits of the conditional, text-unconditional and image-unconditional forwards of ONE image step of
+    configs[1] (L = 2438, N = 1024) — HIP as the sampler launches them (conditional alone, the unconditional pair as one
+    batch-2 launch), oracle bf16, fp32."""
+    if "a" in p8["cache"]:
+        return p8["cache"]["a"]
+    job, model = p8["job"], p8["model"]
     ids = job["input_ids"]
     L = ids.shape[1]
-    sd = synth.synthetic_state_dict_peaked(cfg, synth.peaked_delta(job), device=DEV)
-    model = LLaDAForMultiModalGeneration.from_state_dict(synth.full_config(cfg), sd, device=DEV, max_batch=2)
-    sd = {k: v.cpu() for k, v in sd.items()}
     N, nl = job["seq_len"], job["newline_every"]
     pos = [i for i in range(job["image_start"], job["image_start"] + N + N // nl) if int(ids[0, i]) != synth.NEW_LINE]
-    unc = ids.clone()
-    unc[0, :job["uncon_image"].shape[1]] = job["uncon_image"][0]
+    unc2 = ids.repeat(2, 1)
+    unc2[0, :job["uncon_text"].shape[1]] = job["uncon_text"][0]
+    unc2[1, :job["uncon_image"].shape[1]] = job["uncon_image"][0]
     lo, hi = synth.TEXT_VOCAB, synth.TEXT_VOCAB + synth.CODEBOOK
     rows = torch.tensor(pos, dtype=torch.int32, device=DEV)
+    model.forward_body(ids.to(DEV))
+    hc = model.head_rows(rows, lo, hi).float().cpu()
+    model.forward_body(unc2.to(DEV))
+    hu = model.head_rows(torch.cat([rows, rows + L]), lo, hi).float().cpu()
+    allx = torch.cat([ids, unc2], 0)
+    ob = p8["oracle_rows"](allx, pos, lo, hi)
+    of = p8["oracle_rows"](allx, pos, lo, hi, fp32=True)
+    out = dict(pos=pos, hip=(hc, hu[:len(pos)], hu[len(pos):]), oracle=tuple(ob), fp32=tuple(of))
+    p8["cache"]["a"] = out
+    return out
 
-    def hip(x):
-        model.forward_body(x.to(DEV))
-        return model.head_rows(rows, lo, hi).float().cpu()
 
-    def cfg_combine(c, u):   # parallel_generator.py:282-295 at cfg_scale = 0: bf16 tensors, one rounding per operation
-        c, u = c.to(torch.bfloat16), u.to(torch.bfloat16)
-        return (c + 4.0 * (c - u)).float()
+@pytest.mark.parametrize("cfg_scale,cfg_img", [(0.0, 4.0), (3.0, 4.0)])
+def test_peaked_post_cfg_decisions_at_8b_depth(peaked8b, cfg_scale, cfg_img):
+    """One image step of configs[1] (L = 2438, N = 1024) on a PEAKED 32-block, d = 4096 checkpoint through the CFG combine of
+    parallel_generator.py:282-295 in the reference's bf16 order (the C oracle of it, pinned by tests/golden), arg-max:
+    HIP vs the CPU oracle vs the same weights in fp32.  (0, 4): BASELINE configs[1]'s dual branch; (3, 4): configs[4]'s
+    TRIPLE branch — c + 3 (c - u_text) + 4 (c - u_img), all three forwards contribute."""
+    from oracle import sampler_oracle as so
 
-    hip_f = cfg_combine(hip(ids), hip(unc))
-    torch.set_num_threads(min(32, torch.get_num_threads()))
+    br = _a_branches(peaked8b)
+    job, pos = peaked8b["job"], br["pos"]
+    ids = job["input_ids"]
+    lo = synth.TEXT_VOCAB
 
-    def oracle(x, sdd):
-        h = llada_oracle.forward_hidden(sdd, cfg, x)
-        return llada_oracle.head(sdd, cfg, h[:, pos], lo, hi)[0].float()
+    def decide(c, ut, ui):   # the reference's combine + soft-max + arg-max on bf16 logits
+        cb, tb, ib = (t.to(torch.bfloat16)[None].contiguous() for t in (c, ut, ui))
+        return so.image_probs(cb, tb, ib, float(cfg_scale), float(cfg_img))[0][0].to(torch.int64)
 
-    ora_f = cfg_combine(oracle(ids, sd), oracle(unc, sd))
-    sd32 = {k: v.float() for k, v in sd.items()}   # exact arithmetic on the same bf16-representable weights
-    c32, u32 = oracle(ids, sd32), oracle(unc, sd32)
-    del sd32
-    exact = c32 + 4.0 * (c32 - u32)
-    a_hip, a_ora, a_ex = hip_f.argmax(-1), ora_f.argmax(-1), exact.argmax(-1)
+    a_hip, a_ora = decide(*br["hip"]), decide(*br["oracle"])
+    c32, t32, i32 = br["fp32"]
+    exact = c32 + (cfg_scale * (c32 - t32) if cfg_scale else 0.0) + (cfg_img * (c32 - i32) if cfg_img else 0.0)
+    a_ex = exact.argmax(-1)
     want = torch.tensor([int(ids[0, p - synth.peaked_delta(job)]) - lo for p in pos])
     n = len(pos)
-    top2 = exact.topk(2, -1).values
-    rep = {"slots": n, "hip_vs_oracle": (a_hip == a_ora).float().mean().item(), "hip_vs_fp32": (a_hip == a_ex).float().mean().item(),
-           "oracle_vs_fp32": (a_ora == a_ex).float().mean().item(), "fp32_copies_planted_token": (a_ex == want).float().mean().item(),
-           "distinct_codes": len(set(a_ex.tolist())),
-           "min_margin_over_max_err_hip": ((top2[:, 0] - top2[:, 1]) / (hip_f - exact).abs().max(-1).values.clamp_min(1e-9)).min().item()}
+    rep = {"cfg_scale": cfg_scale, "cfg_img": cfg_img, "slots": n, "hip_vs_oracle": (a_hip == a_ora).float().mean().item(),
+           "hip_vs_fp32": (a_hip == a_ex).float().mean().item(), "oracle_vs_fp32": (a_ora == a_ex).float().mean().item(),
+           "fp32_copies_planted_token": (a_ex == want).float().mean().item(), "distinct_codes": len(set(a_ex.tolist())),
+           "text_branch_differs_from_cond_argmax": (br["fp32"][1].argmax(-1) != c32.argmax(-1)).float().mean().item()}
     sigma = (rep["oracle_vs_fp32"] * (1 - rep["oracle_vs_fp32"]) / n) ** 0.5
     rep["one_sigma_of_oracle_vs_fp32"] = sigma
     print("peaked checkpoint, one image step at 8B depth through the CFG combine:", rep)
-    save_parity("peaked_post_cfg_full_depth_8b", rep)
+    save_parity("peaked_post_cfg_full_depth_8b" + ("_triple_branch" if cfg_scale else ""), rep)
     assert rep["distinct_codes"] > 300
     assert rep["hip_vs_oracle"] >= 0.98, rep
     assert rep["hip_vs_fp32"] >= rep["oracle_vs_fp32"] - max(sigma, 1.0 / n), rep
+
+
+def test_m_teacher_forced_step_at_8b_depth(peaked8b):
+    """MMaDA-Parallel-M, ONE step of interleave_generate (models/modeling_mmada.py:163-246) at 8B depth and width in the M
+    layout: the batch-2 forward (cond || uncond) at L = 2349 (Lp = 2352 — not the 2440-row panels of every A test), then the text
+    step (cond + 2.5 (uncond - cond), fp64 soft-max confidence, top-k commit: mmada_text_select_cfg on the real head rows) and
+    the image step's (1 + 4) cond - 4 uncond soft-max (mmada_image_probs_m), HIP vs the C oracle of the same lines fed with
+    the CPU oracle's logits, vs fp32.  The checkpoint is the A job's (copy distance 1084): the 18 image slots whose source lies
+    before the input image codes have no planted prediction and are left out."""
+    from mmada_parallel_amd import abi
+    from oracle import sampler_oracle as so
+
+    model = peaked8b["model"]
+    lib, h = model._lib, model._handle
+    mj = synth.m_peaked_job()
+    N, T, P, L = mj["N"], mj["T"], mj["P"], mj["L"]
+    assert L == 2349
+    tail = torch.cat([torch.tensor([mj["soi"]]), torch.full((N,), synth.MASK), torch.tensor([mj["eoi"], mj["bos"]]),
+                      torch.full((T - 1,), synth.MASK)])
+    both = torch.stack([torch.cat([mj["input_ids"], tail]), torch.cat([mj["uncond_input_ids"], tail])], 0)
+    i0, ts = mj["img_start"], mj["text_start"]
+    lo, CB, V = synth.TEXT_VOCAB, synth.CODEBOOK, model.vocab
+    delta = synth.peaked_delta(peaked8b["job"])
+    live = torch.tensor([2 <= (i0 + j) - delta < 2 + N for j in range(N)])
+    K = 48
+    ids_dev = both.to(DEV)
+    model.forward_body(ids_dev, consumed=(i0, L))
+    ar = torch.arange(ts, L, dtype=torch.int32, device=DEV)
+    pm = torch.arange(i0, i0 + N, dtype=torch.int32, device=DEV)
+    tl = model.head_rows(torch.cat([ar, ar + L]), 0, V)
+    il = model.head_rows(torch.cat([pm, pm + L]), lo, lo + CB)
+    st = abi.stream_ptr()
+    k_dev = torch.tensor([K], dtype=torch.int32, device=DEV)
+    scratch = torch.empty(T * 16, dtype=torch.uint8, device=DEV)
+    hip_ids = ids_dev[:1].clone()
+    abi.check(lib.mmada_text_select_cfg(h, tl[:T].data_ptr(), tl[T:].data_ptr(), 2.5, None, 1, T, V, V, hip_ids.data_ptr(), L, ts,
+                                        k_dev.data_ptr(), scratch.data_ptr(), st), "mmada_text_select_cfg")
+    probs = torch.empty((N, CB), dtype=torch.bfloat16, device=DEV)
+    am = torch.empty((1, N), dtype=torch.int32, device=DEV)
+    pmax = torch.empty((1, N), dtype=torch.bfloat16, device=DEV)
+    abi.check(lib.mmada_image_probs_m(h, il[:N].data_ptr(), il[N:].data_ptr(), 1, N, CB, 4.0, probs.data_ptr(), am.data_ptr(),
+                                      pmax.data_ptr(), st), "mmada_image_probs_m")
+    torch.cuda.synchronize()
+    hip_x0 = scratch[T * 8: T * 12].view(torch.int32).cpu().to(torch.int64)
+    hip_text = hip_ids[0, ts:].cpu()
+    hip_am = am[0].cpu().to(torch.int64)
+
+    def oracle_side(fp32):
+        rows = list(range(i0, i0 + N)) + list(range(ts, L))
+        full = peaked8b["oracle_rows"](both, rows, 0, V, fp32=fp32)     # [2] x [N + T, V]
+        return [f[:N, lo:lo + CB] for f in full], [f[N:] for f in full]
+
+    (ic, iu), (tc, tu) = oracle_side(False)
+    o_ids, _, o_x0 = so.text_select_cfg(tc.to(torch.bfloat16)[None].contiguous(), tu.to(torch.bfloat16)[None].contiguous(), 2.5,
+                                        both[:1], ts, [K], mask_id=synth.MASK)
+    o_am = so.image_probs_m(ic.to(torch.bfloat16)[None].contiguous(), iu.to(torch.bfloat16)[None].contiguous(), 4.0)[0][0].to(torch.int64)
+    (ic32, iu32), (tc32, tu32) = oracle_side(True)
+    e_am = ((1 + 4.0) * ic32 - 4.0 * iu32).argmax(-1)
+    e_x0 = (tc32 + 2.5 * (tu32 - tc32)).argmax(-1)
+    masked = both[0, ts:] == synth.MASK
+    o_x0 = o_x0[0].to(torch.int64)
+    nl = int(live.sum())
+    rep = {"L": L, "image_slots_with_a_planted_source": nl,
+           "image_argmax_hip_vs_oracle": (hip_am[live] == o_am[live]).float().mean().item(),
+           "image_argmax_hip_vs_fp32": (hip_am[live] == e_am[live]).float().mean().item(),
+           "image_argmax_oracle_vs_fp32": (o_am[live] == e_am[live]).float().mean().item(),
+           "image_distinct_codes": len(set(e_am[live].tolist())),
+           "text_x0_hip_vs_oracle": (hip_x0[masked] == o_x0[masked]).float().mean().item(),
+           "text_x0_hip_vs_fp32": (hip_x0[masked] == e_x0[masked]).float().mean().item(),
+           "text_x0_oracle_vs_fp32": (o_x0[masked] == e_x0[masked]).float().mean().item(),
+           "text_committed": int((hip_text != synth.MASK).sum() - (both[0, ts:] != synth.MASK).sum()),
+           "text_committed_positions_equal": float(((hip_text != synth.MASK) == (o_ids[0, ts:] != synth.MASK)).float().mean()),
+           "text_committed_tokens_equal_where_both": float((hip_text == o_ids[0, ts:])[(hip_text != synth.MASK) & (o_ids[0, ts:] != synth.MASK)].float().mean())}
+    print("M layout, one teacher-forced step at 8B depth:", rep)
+    save_parity("m_teacher_forced_step_full_depth_8b", rep)
+    assert rep["text_committed"] == K
+    assert rep["image_distinct_codes"] > 300
+    s_img = (rep["image_argmax_oracle_vs_fp32"] * (1 - rep["image_argmax_oracle_vs_fp32"]) / nl) ** 0.5
+    assert rep["image_argmax_hip_vs_oracle"] >= 0.98 and rep["image_argmax_hip_vs_fp32"] >= rep["image_argmax_oracle_vs_fp32"] - max(s_img, 1.0 / nl), rep
+    assert rep["text_x0_hip_vs_oracle"] >= 0.98 and rep["text_committed_tokens_equal_where_both"] >= 0.98, rep
+    assert rep["text_committed_positions_equal"] >= 0.9, rep
 
 
 def test_flat_weights_post_cfg_envelope_over_many_jobs():
@@ -241,3 +356,59 @@ def test_flat_weights_post_cfg_envelope_over_many_jobs():
     save_parity("post_cfg_flat_envelope_many_jobs", rep)
     sigma = (rep["oracle_vs_fp32"] * (1 - rep["oracle_vs_fp32"]) / n) ** 0.5
     assert rep["hip_batch2_vs_fp32"] >= rep["oracle_vs_fp32"] - 4 * sigma - 0.01, rep
+
+
+def test_m_peaked_free_running_interleave_generate_equals_the_reference_recording():
+    """MMaDA-Parallel-M END TO END with a real forward (round-4 review: the M sampler had only run on stub logits on the GPU):
+    MMadaModelLM.interleave_generate free-running on the peaked checkpoint at BASELINE configs[3] geometry — L = 2349, every step
+    ONE batch-2 (cond || uncond) HIP forward, mmada_text_select_cfg / mmada_image_probs_m / mmada_image_commit_m on the real head
+    rows, text_cfg 2.5, image_cfg 4 — against the ids the UNMODIFIED reference (its own sampler on its own LLaDAModelLM,
+    oracle/gen_golden.py gen_m_peaked -> tests/golden/m_peaked_traj.*.npz) passed to every forward, with the reference's
+    multinomial / uniform draws replayed (SeededRng).  models/modeling_mmada.py:117-248, MMaDA-Parallel-M/inference.py:113-127."""
+    from types import SimpleNamespace
+
+    from mmada_parallel_amd import MMadaModelLM
+    from oracle.interleave_oracle import SeededRng
+
+    z, _ = golden_float("m_peaked_traj")
+    ref = torch.from_numpy(z["calls"].astype(np.int64))          # [steps, 2, L]
+    job, kw = synth.m_peaked_job(), dict(synth.M_PEAKED_KW)
+    cfg = synth.CFG_PEAKED
+    assert ref.shape == (kw["text_steps"], 2, job["L"]) and job["L"] == 2349
+    sd = synth.synthetic_state_dict_peaked(cfg, job["delta"], beta=synth.M_PEAKED_BETA)
+    model = MMadaModelLM.from_state_dict(synth.full_config(cfg), sd, device=DEV, max_batch=2)
+
+    class Tok:
+        bos_token_id = job["bos"]
+
+        def __len__(self):
+            return job["text_vocab"]
+
+    cfgobj = SimpleNamespace(model=SimpleNamespace(mmada=SimpleNamespace(num_vq_tokens=job["N"], codebook_size=job["codebook"])),
+                             dataset=SimpleNamespace(preprocessing=SimpleNamespace(max_seq_length=job["T"])))
+    trace = []
+    img, text = model.interleave_generate(job["input_ids"], job["uncond_input_ids"],
+                                          reserved_token_mapping={"<|soi|>": job["soi"], "<|eoi|>": job["eoi"]}, config=cfgobj,
+                                          uni_prompting=SimpleNamespace(text_tokenizer=Tok()), rng=SeededRng(53), trace=trace, **kw)
+    got = torch.stack(trace, 0)
+    assert got.shape == ref.shape
+    i0, ts, N = job["img_start"], job["text_start"], job["N"]
+    gi, ri = got[:, 0, i0:i0 + N], ref[:, 0, i0:i0 + N]
+    both = (gi != synth.MASK) & (ri != synth.MASK)
+    per_call = (got == ref).float().mean((1, 2))
+    img_ref, text_ref = torch.from_numpy(z["img"]), torch.from_numpy(z["text"])
+    rep = {"forwards": int(got.shape[0]), "L": int(got.shape[2]), "calls_identical": int((got == ref).all(2).all(1).sum()),
+           "ids_equal_fraction_over_all_calls": (got == ref).float().mean().item(), "worst_call_ids_equal": per_call.min().item(),
+           "text_span_ids_equal_over_all_calls": (got[:, 0, ts:] == ref[:, 0, ts:]).float().mean().item(),
+           "image_tokens_equal_where_both_unmasked": ((gi == ri) & both).sum().item() / max(1, int(both.sum())),
+           "image_mask_pattern_equal": ((gi == synth.MASK) == (ri == synth.MASK)).float().mean().item(),
+           "final_image_ids_agreement": (img.cpu() == img_ref).float().mean().item(),
+           "final_text_ids_agreement": (text.cpu() == text_ref).float().mean().item(),
+           "distinct_image_ids": len(set(img.cpu().reshape(-1).tolist())), "distinct_text_ids": len(set(text.cpu().reshape(-1).tolist())),
+           "reference_min_one_minus_text_conf": float(z["one_minus_top_text_conf"].min())}
+    print("M variant, peaked checkpoint, free-running interleave_generate vs the reference's recording:", rep)
+    save_parity("m_peaked_free_running_vs_reference", rep)
+    assert rep["ids_equal_fraction_over_all_calls"] >= 0.99 and rep["worst_call_ids_equal"] >= 0.98, rep
+    assert rep["text_span_ids_equal_over_all_calls"] >= 0.99 and rep["image_tokens_equal_where_both_unmasked"] >= 0.99, rep
+    assert rep["final_image_ids_agreement"] >= 0.99 and rep["final_text_ids_agreement"] >= 0.99, rep
+    assert rep["distinct_image_ids"] > 300, "the planted circuit must give position-dependent predictions"

@@ -257,6 +257,45 @@ def test_peaked_trajectory_matches_reference():
         assert (got == ref).float().mean() >= 0.995
 
 
+def test_m_peaked_trajectory_matches_reference():
+    """MMaDA-Parallel-M end to end: oracle/interleave_oracle.py driven by oracle/llada_oracle.py on the peaked checkpoint at
+    BASELINE configs[3] geometry (L = 2349, batch-2 forwards, text_cfg 2.5, image_cfg 4, 24 steps of which 8 image steps) must
+    reproduce the ids the UNMODIFIED reference — MMadaModelLM.interleave_generate on the M tree's own LLaDAModelLM,
+    oracle/gen_golden.py gen_m_peaked — passed to every forward, and its outputs, with the reference's multinomial / uniform
+    draws replayed: bit for bit on a CPU of the recording's class, >= 99.5 % on any other.  The oracle's head runs on the rows
+    the sampler reads (image rows x codebook slab, text rows x vocabulary)."""
+    from oracle import interleave_oracle as io_
+    from oracle.interleave_oracle import SeededRng
+
+    z, same = golden_float("m_peaked_traj")
+    ref = torch.from_numpy(z["calls"].astype(np.int64))
+    cfg, job, kw = synth.CFG_PEAKED, synth.m_peaked_job(), dict(synth.M_PEAKED_KW)
+    assert float(z["one_minus_top_text_conf"].min()) > 0.0, "an fp64 text confidence of exactly 1.0: torch.topk would order ties"
+    sd = synth.synthetic_state_dict_peaked(cfg, job["delta"], beta=synth.M_PEAKED_BETA)
+    i0, ts, N, L = job["img_start"], job["text_start"], job["N"], job["L"]
+    lo, V = job["text_vocab"], cfg["vocab_size"]
+    buf = torch.zeros((2, L, V), dtype=torch.bfloat16)
+
+    def model_fn(both):
+        h = llada_oracle.forward_hidden(sd, cfg, both)
+        buf[:, i0:i0 + N, lo:lo + job["codebook"]] = llada_oracle.head(sd, cfg, h[:, i0:i0 + N], lo, lo + job["codebook"])
+        buf[:, ts:] = llada_oracle.head(sd, cfg, h[:, ts:])
+        return buf
+
+    trace = []
+    img, text = io_.generate(model_fn, job["input_ids"], job["uncond_input_ids"], kw["text_cfg"], kw["image_cfg"], kw["text_steps"],
+                             kw["image_steps"], job["soi"], job["eoi"], job["bos"], synth.MASK, lo, N, job["codebook"], job["T"],
+                             kw["image_temperature"], SeededRng(53), text_temperature=kw["text_temperature"], trace=trace)
+    got = torch.stack(trace, 0)
+    assert got.shape == ref.shape == (kw["text_steps"], 2, 2349)
+    assert len(set(z["img"].reshape(-1).tolist())) > 300
+    if same:
+        assert torch.equal(got, ref), f"first differing call: {int((got != ref).any(2).any(1).nonzero()[0])}"
+        assert torch.equal(img, torch.from_numpy(z["img"])) and torch.equal(text, torch.from_numpy(z["text"]))
+    else:
+        assert (got == ref).float().mean() >= 0.995
+
+
 def _check_dllm_cache(z, exact):
     """oracle/llada_oracle.py forward_logits_cached replayed over the fixture's script (oracle/gen_golden.py
     dllm_cache_script) must return the reference's logit cache after every call."""

@@ -37,7 +37,7 @@ def main():
     args = ap.parse_args()
     forms = [int(f) for f in args.forms.split(",")]
     if max(forms) > 2:   # diagnostic variants live in the -DMMADA_TUNE build (prebuilt copies travel with the snapshot)
-        from tools.tune.build_tune import PRODUCT_TUNE_LIB, build_product_tune
+        from tools.build_tune import PRODUCT_TUNE_LIB, build_product_tune
         os.environ["MMADA_MI355X_LIB"] = PRODUCT_TUNE_LIB if os.environ.get("MMADA_TUNE_PREBUILT") == "1" and os.path.exists(PRODUCT_TUNE_LIB) else build_product_tune()
     lib = abi.lib()
     cfg = synth.CFG_8B

@@ -1,7 +1,10 @@
 #!/usr/bin/env python
-"""Time the GEMM tile/pipeline variants (tools/tune/gemm_var.hip, built into tools/libmmada_tune.so) on the four projection shapes of the 8B block.
+"""Time the product GEMM's configurations (the -DMMADA_TUNE build of mmada_parallel_amd/csrc: tools/build_tune.py ->
+tools/libmmada_mi355x_tune.so — the same sources as the product, plus diagnostic configurations) on the projection shapes of
+the 8B block.  Variant codes: 100 = the planner's pick; 300 + c = the 8-phase kernel's configuration c (0..3 ship; 4.. are
+tuning-build extras, 9..15 DIAGNOSTIC builds with wrong results: csrc/gemm8.hip launch_epi8); 1000 + BM = the 16-wave kernel.
 
-    python tools/gemm_sweep.py [--variants 0,1,2] [--m 2438,4876]
+    python tools/gemm_sweep.py [--variants 100,300,301,302,303] [--m 2440,4880] [--order 0,1,2]
 Random bf16 operands (zero-filled operands clock ~20 % higher: never bench on zeros).  Interleaved rounds, median.
 """
 import argparse
@@ -11,15 +14,16 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
-from tools.tune.build_tune import build as build_tune  # noqa: E402
+from tools.build_tune import build_product_tune  # noqa: E402
 
 SHAPES = {"qkv": (12288, 4096), "o": (4096, 4096), "gateup": (24576, 4096), "down": (4096, 12288)}
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--variants", default="0,1,2,3,4,5,6,7,8,9,10,11")
-    ap.add_argument("--m", default="2438,4876")
+    ap.add_argument("--variants", default="100,300,301,302,303")
+    ap.add_argument("--m", default="2440,4880")
+    ap.add_argument("--order", default=None, help="comma list of gemm_tile_order values to time per variant (default: the product's)")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--shapes", default=None, help="name:N:K,... instead of the four TP=1 projection shapes")
     ap.add_argument("--check", action="store_true")
@@ -32,8 +36,20 @@ def main():
         shapes = {n: (int(a), int(b)) for n, a, b in (x.split(":") for x in args.shapes.split(","))}
     import ctypes
 
-    lib = ctypes.CDLL(build_tune())
-    lib.mmada_gemm_variant.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    lib = ctypes.CDLL(build_product_tune())
+    lib.mmada_gemm_bt.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
+    lib.mmada_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    lib.mmada_last_error.restype = ctypes.c_char_p
+
+    class _V:
+        @staticmethod
+        def mmada_gemm_variant(v, A, W, C, M, N, K, st):
+            lib.mmada_set_option(b"gemm_config", -1 if v == 100 else (v - 300 if 300 <= v < 1000 else v))
+            rc = lib.mmada_gemm_bt(A, W, C, M, N, K, st)
+            lib.mmada_set_option(b"gemm_config", -1)
+            return rc
+
+    lib_raw, lib = lib, _V
     dev = "cuda:0"
     variants = [int(v) for v in args.variants.split(",")]
     st = torch.cuda.current_stream().cuda_stream
