@@ -89,9 +89,7 @@ int mmada_bind_layer(mmada_handle* h, int layer,
 /* Bytes of activation workspace needed for a forward of B sequences of length L (all equal length: the
  * reference never masks padding). */
 size_t mmada_workspace_bytes(const mmada_handle* h, int B, int L);
-/* Caller-owned device buffer (>= mmada_workspace_bytes for the largest (B,L) used), 256-byte aligned.  The call zeroes the
- * buffer's first 64 KiB (a synchronous hipMemset): the arrival counters of the attention kernel's key split, which every
- * launch leaves at zero again.  Nobody else may write there while the handle owns the buffer. */
+/* Caller-owned device buffer (>= mmada_workspace_bytes for the largest (B,L) used), 256-byte aligned. */
 int mmada_set_workspace(mmada_handle* h, void* ws, size_t bytes);
 
 /* ---- transformer forward -------------------------------------------------------------------------------------
@@ -333,26 +331,20 @@ int mmada_profile_begin(mmada_handle* h, int layer);
 int mmada_profile_end(mmada_handle* h, int32_t* count_out /*[5]*/, double* ms_out /*[5]*/, double* flops_out /*[5]*/);
 
 /* ---- measurement / test switches (process-wide; no reference counterpart) --------------------------------------------
- * Every choice below EXCEPT "attention_split" is between kernels that produce BIT-IDENTICAL results
- * (tests/test_gpu_kernels.py); the switches exist so that sweeps and A/B tests can pin one.
- *   "attention_split" 1 (default): sequences of more than 2048 rows cut the KEYS of their last query tiles (rows >= 2048: the
- *                    tiles beyond the whole rounds 32 heads x 16 tiles fill) 16 / n_tiles ways; fp32 partials, combined in
- *                    split order by the last workgroup to arrive (csrc/attention.h: attn_split_plan — a function of L alone, so
- *                    batch invariance and the consumed-row window's bit identity hold).  0: every query tile walks every key
- *                    (the rows >= 2048 then differ in the last bf16 bit of some outputs: another fp32 summation order)
- *   "attention_skip_idle" 1 (default): waves without a live query row skip their matrix blocks; 0: they compute and discard
+ * Every choice below is between kernels that produce BIT-IDENTICAL results (tests/test_gpu_kernels.py); the switches exist
+ * so that sweeps and A/B tests can pin one.
  *   "gemm_config"    -1 automatic (default: the cost model of csrc/gemm.hip); 0..3 the 8-phase kernel's tile configuration
  *                    (320x256, 256x256, 160x256, 320x128); 1000 + BM the 16-wave kernel with that row-tile height
  *   "attention_form" -1 automatic (default: MMADA_ATTN_FORM or 1); 0 the round-2 issue order; 1 software-pipelined matrix
- *                    blocks (fragments prefetched in registers, pinned issue order); 2 attention64 (64 query rows per wave,
- *                    one wave per SIMD, hand-owned accumulator file)
+ *                    blocks (fragments prefetched in registers, pinned issue order)
  *   "gemm_silu_lut"  1 (default): the 8-phase SwiGLU epilogue reads SiLU of the bf16 gate value from a 10-KiB table in the LDS (filled on
  *                    the device by the function it replaces; untabulated values are evaluated); 0: always evaluate
  *   "gemm_short_tiles" 1 (default): the 320-row configurations use a row-tile pitch of 304 when ntm - 1 tiles of 304 rows and
  *                    one of <= 320 cover M (M = B * 2440: 5 % fewer MFMAs in all but the last row tile); 0: full height
  *   "probe_variant"  MFMA shape / occupancy of mmada_mfma_probe (tools/probe_variants.py)
- *   "gemm_tile_order" 0 (default): the 8-phase kernel walks bands of 1024 columns, all row tiles per band; GM * 100 + GN: groups of GM
- *                    row tiles x GN column tiles per XCD-round (the FETCH_SIZE sweep, tools/gemm_sweep.py --order)
+ *   "gemm_tile_order" 0 (default): the 8-phase kernel's per-tile default — groups of 4 row tiles x 8 column tiles for the 320x256
+ *                    tile, bands of 1024 columns x all row tiles for the others; GM * 100 + GN: groups of GM row tiles x GN column
+ *                    tiles per XCD-round (9904 = the round-4 order; the FETCH_SIZE sweep, tools/tile_order_fetch.py)
  *   "tp_allow_single_rank" 1: mmada_comm_create accepts tp_size == 1 and mmada_forward_body runs a connected one-rank handle through
  *                    the tensor-parallel path (every line of the RCCL / pull transports executes; bit-identical to the plain
  *                    forward: tests/test_gpu_tp.py).  0 (default): tp_size must be 2..8 */
@@ -369,6 +361,11 @@ int mmada_gemm_plan(int M, int N, int K);
  * of device scratch.  iters = 32768 is ~50 ms per launch. */
 size_t mmada_mfma_probe_bytes(void);
 int mmada_mfma_probe(const void* data, void* sink, int iters, int launches, void* stream, double* tflops_out, double* ms_out);
+
+/* ---- CU-mask probe (measurement only): where the workgroups of a grid run on a stream created with `mask` (words x 32 bits, bit i
+ * = "CU i" of hipExtStreamCreateWithCUMask): out_host[b] = XCC_ID | HW_ID << 8 of workgroup b.  tools/cu_mask_probe.py maps mask bits
+ * to (XCD, SE, CU) with it — the layout mmada_comm_set_partition relies on. */
+int mmada_probe_cu_mask(const uint32_t* mask, int words, uint32_t* out_host, int n_blocks);
 
 /* ---- rounding probe (tests only) -----------------------------------------------------------------------------------------
  * out[i] = the library's fp32 -> bf16 conversion (f2bf of csrc/common.h, used by every epilogue and elementwise kernel) of
@@ -391,9 +388,17 @@ int mmada_probe_f2bf(const float* in, uint16_t* out, int64_t n, void* stream);
  *   mmada_comm_connect_rccl  RCCL transport (ncclReduceScatter / ncclAllGather issued by the library); unique_id128 from
  *                            mmada_comm_unique_id on rank 0, distributed by the host; librccl_path NULL = "librccl.so"
  *                            (pass the path of the library the process already has loaded, e.g. torch/lib/librccl.so)
- *   mmada_comm_set_mode      switch between connected transports (1 pull, 2 RCCL); 3 = DIAGNOSTIC "no exchange": the
+ *   mmada_comm_set_mode      switch between connected transports (1 pull, 2 RCCL, 4 copy engines: the mapped peer buffers of
+ *                            the pull transport, bytes moved by hipMemcpyAsync / SDMA into local staging, the owner kernel
+ *                            reads local memory only, the all-gather half is copies); 3 = DIAGNOSTIC "no exchange": the
  *                            forward runs its owner-side kernels on this rank's own partial sums only (no peer traffic,
  *                            no hand-off; wrong values) — bench.py times it to report the exposed exchange time
+ *   mmada_comm_set_partition exchange_cus > 0 (a multiple of 8): the exchange stream owns that many CUs (the same number on
+ *                            every XCD, hipExtStreamCreateWithCUMask) and the forward's compute kernels run on a library
+ *                            stream masked to the other CUs, forked from / joined to the caller's stream by events — the
+ *                            exchange is concurrent with the GEMMs by construction instead of by stream priority; 0 removes
+ *                            the partition.  mmada_comm_partition returns the current value, mmada_comm_streams the two
+ *                            library streams (probes)
  *   mmada_comm_rccl_nranks   ranks of the RCCL communicator this handle created (ncclCommCount), 0 if none
  *   mmada_comm_status        transport in use, sticky error (a peer never arrived within MMADA_TP_TIMEOUT_S, default 20 s:
  *                            the device is never hung, the results are void), whether the counters are fine-grained
@@ -407,6 +412,9 @@ int mmada_comm_connect_local(mmada_handle* h, mmada_handle* const* ranks);
 int mmada_comm_unique_id(void* out128, const char* librccl_path);
 int mmada_comm_connect_rccl(mmada_handle* h, const void* unique_id128, const char* librccl_path);
 int mmada_comm_set_mode(mmada_handle* h, int mode);
+int mmada_comm_set_partition(mmada_handle* h, int exchange_cus);
+int mmada_comm_partition(mmada_handle* h);
+int mmada_comm_streams(mmada_handle* h, void** exchange_out, void** compute_out);
 int mmada_comm_rccl_nranks(mmada_handle* h);
 /* Hand-off timeout of the pull transport in seconds (<= 0: MMADA_TP_TIMEOUT_S or 20 s); clears a sticky error. */
 int mmada_comm_set_timeout(mmada_handle* h, double seconds);
@@ -452,8 +460,7 @@ int mmada_gemm_swiglu_bt(const void* A, const void* W, void* C, int M, int N, in
 /* RMSLayerNorm.forward (model/modeling_llada.py:301-329): out = w * bf16(x * rsqrt(mean(x²)+eps)). */
 int mmada_rmsnorm(const void* x, const void* w, void* out, int rows, int d, float eps, void* stream);
 /* Unmasked non-causal SDPA over [B,H,L,128] q/k/v (bf16, contiguous) → out [B,L,H*128]
- * (model/modeling_llada.py:643-679,731-744). Uses the handle's workspace for the padded q / k, the K-major V copy and the
- * key-split scratch. */
+ * (model/modeling_llada.py:643-679,731-744). Uses the handle's workspace for the padded q / k and the K-major V copy. */
 int mmada_sdpa(mmada_handle* h, const void* q, const void* k, const void* v, void* out, int B, int H, int Hkv, int L,
                void* stream);
 

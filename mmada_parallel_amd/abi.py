@@ -98,7 +98,11 @@ SIGNATURES = {
     "mmada_comm_connect_local": (c_int, [c_void_p, C.POINTER(c_void_p)]),
     "mmada_comm_unique_id": (c_int, [c_void_p, C.c_char_p]),
     "mmada_comm_connect_rccl": (c_int, [c_void_p, c_void_p, C.c_char_p]),
+    "mmada_probe_cu_mask": (c_int, [c_void_p, c_int, c_void_p, c_int]),
     "mmada_comm_set_mode": (c_int, [c_void_p, c_int]),
+    "mmada_comm_set_partition": (c_int, [c_void_p, c_int]),
+    "mmada_comm_partition": (c_int, [c_void_p]),
+    "mmada_comm_streams": (c_int, [c_void_p, c_void_p, c_void_p]),
     "mmada_comm_rccl_nranks": (c_int, [c_void_p]),
     "mmada_comm_set_timeout": (c_int, [c_void_p, C.c_double]),
     "mmada_comm_status": (c_int, [c_void_p, C.POINTER(c_int), C.POINTER(c_int), C.POINTER(c_int), c_void_p]),

@@ -39,6 +39,7 @@ int mmada_create(const mmada_cfg* cfg, const float* inv_freq_host, mmada_handle*
     if (cfg->mlp_hidden % (64 * cfg->tp_size)) return mm_fail("mmada_create: mlp_hidden must be a multiple of 64*tp_size");
     if (cfg->d_model % 64) return mm_fail("mmada_create: d_model must be a multiple of 64");
     if (cfg->max_seq <= 0 || cfg->n_layers <= 0 || cfg->vocab <= 0) return mm_fail("mmada_create: bad sizes");
+    if (gemm_prepare_device()) return 1;   // no launch of this handle ever allocates or synchronises (gemm.hip)
     mmada_handle* h = new mmada_handle();
     h->cfg = *cfg;
     h->hq_l = cfg->n_heads / cfg->tp_size;
@@ -139,9 +140,6 @@ size_t mmada_workspace_bytes(const mmada_handle* h, int B, int L) {
 int mmada_set_workspace(mmada_handle* h, void* ws, size_t bytes) {
     if (!h || !ws) return mm_fail("mmada_set_workspace: null argument");
     if (((uintptr_t)ws) & 255) return mm_fail("mmada_set_workspace: workspace must be 256-byte aligned");
-    if (bytes < 65536) return mm_fail("mmada_set_workspace: %zu bytes is below the 64 KiB header", bytes);
-    // the first 64 KiB hold the arrival counters of the attention kernel's key split: zero when handed over, zero after every launch
-    MM_CHECK_HIP(hipMemset(ws, 0, 65536));
     h->ws = (char*)ws;
     h->ws_bytes = bytes;
     h->B = h->L = 0;
@@ -159,7 +157,6 @@ static int apply_carve(mmada_handle* h, int B, int L, hipStream_t s) {
     h->att = (bf16_t*)(h->ws + c.att); h->hbuf = (bf16_t*)(h->ws + c.h); h->q = (bf16_t*)(h->ws + c.q);
     h->k = (bf16_t*)(h->ws + c.k); h->vT = (bf16_t*)(h->ws + c.vT); h->xg = (bf16_t*)(h->ws + c.xg);
     h->rows_all = (int32_t*)(h->ws + c.rows);
-    h->attn_split = h->ws + c.split; h->attn_split_bytes = c.split_bytes;
     h->posmap = (int32_t*)(h->ws + c.posmap);
     // vT columns never written by the QKV epilogue (keys >= Lp; the key order inside a 16-key group is permuted, so
     // start at the last group boundary) are multiplied by P == 0: keep them finite
@@ -232,12 +229,12 @@ int mmada_attn_partial(mmada_handle* h, int layer, void* stream) {
         ProfScope p(h, layer, 1, 4.0 * h->hq_l * orows * (cc ? cc->L : h->L) * 128.0, s);
         if (cc) {  // compact (or all) queries of this call against the slot's keys / values of the whole sequence
             if (launch_attention(h->q, g.k, g.vT, h->att, h->B, h->hq_l, h->hkv_l, cc->L, h->Lp, cc->Lkv, h->Lp,
-                                 h->hq_l * 128, s, 0, h->Lkv, h->attn_split, h->attn_split_bytes)) return 1;
+                                 h->hq_l * 128, s, 0, h->Lkv)) return 1;
         } else if (W) {
             if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, wend, h->Lkv, W,
-                                 h->hq_l * 128, s, wbeg, 0, h->attn_split, h->attn_split_bytes)) return 1;
+                                 h->hq_l * 128, s, wbeg)) return 1;
         } else if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->Lp, h->Lkv, h->Lp,
-                                    h->hq_l * 128, s, 0, 0, h->attn_split, h->attn_split_bytes)) return 1;
+                                    h->hq_l * 128, s)) return 1;
     }
     GemmArgs o{};
     o.A = h->att; o.W = lw.wo; o.C = h->y;
@@ -313,8 +310,6 @@ int mmada_set_option(const char* name, int value) {
     if (!strcmp(name, "gemm_short_tiles")) { gemm8_set_short_tiles(value); return 0; }
     if (!strcmp(name, "gemm_tile_order")) { gemm8_set_tile_order(value); return 0; }
     if (!strcmp(name, "attention_form")) { attention_force_form(value); return 0; }
-    if (!strcmp(name, "attention_split")) { attention_set_split(value); return 0; }
-    if (!strcmp(name, "attention_skip_idle")) { attention_set_skip_idle(value); return 0; }
     if (!strcmp(name, "probe_variant")) { mfma_probe_set_variant(value); return 0; }
     if (!strcmp(name, "tp_allow_single_rank")) { tp_allow_single_rank(value); return 0; }
     return mm_fail("mmada_set_option: unknown option '%s'", name);
@@ -632,16 +627,15 @@ int mmada_sdpa(mmada_handle* h, const void* q, const void* k, const void* v, voi
     hipStream_t s = (hipStream_t)stream;
     const int Lkv = ceil_to(L, 64);
     const size_t qb = align_up((size_t)B * H * Lkv * 128 * 2, 256), kb = align_up((size_t)B * Hkv * Lkv * 128 * 2, 256);
-    const size_t sb = align_up(attention_split_bytes(B, H, L), 256);   // key-split scratch first: its counters are the workspace's first 64 KiB
-    if (!h->ws || sb + qb + 2 * kb > h->ws_bytes) return mm_fail("mmada_sdpa: workspace too small (%zu needed)", sb + qb + 2 * kb);
-    bf16_t* qp = (bf16_t*)(h->ws + sb);
-    bf16_t* kp = (bf16_t*)(h->ws + sb + qb);
-    bf16_t* vt = (bf16_t*)(h->ws + sb + qb + kb);
+    if (!h->ws || qb + 2 * kb > h->ws_bytes) return mm_fail("mmada_sdpa: workspace too small (%zu needed)", qb + 2 * kb);
+    bf16_t* qp = (bf16_t*)h->ws;
+    bf16_t* kp = (bf16_t*)(h->ws + qb);
+    bf16_t* vt = (bf16_t*)(h->ws + qb + kb);
     h->M = 0;  // the resident forward (if any) is clobbered
     if (launch_pad_heads((const bf16_t*)q, qp, B * H, L, Lkv, s)) return 1;
     if (launch_pad_heads((const bf16_t*)k, kp, B * Hkv, L, Lkv, s)) return 1;
     if (launch_transpose_v((const bf16_t*)v, vt, B * Hkv, L, Lkv, s)) return 1;
-    return launch_attention(qp, kp, vt, (bf16_t*)out, B, H, Hkv, L, L, Lkv, L, H * 128, s, 0, 0, h->ws, sb);
+    return launch_attention(qp, kp, vt, (bf16_t*)out, B, H, Hkv, L, L, Lkv, L, H * 128, s);
 }
 
 }  // extern "C"

@@ -1,5 +1,6 @@
-// attention.h — what the attention kernels of attention.hip (4 waves x 32 query rows) and attention64.hip (4 waves x 64
-// query rows, one wave per SIMD) share: tile constants, launch arguments, single-instruction maxima, LDS addressing.
+// attention.h — tile constants, launch arguments, single-instruction maxima and LDS addressing of the attention kernels of
+// attention.hip (4 waves x 32 query rows).  (Round 4's attention64.hip — 64 query rows per wave, one wave per SIMD, a hand-owned
+// accumulator file: bit-identical and not faster — was removed in round 5; DESIGN.md §3 keeps what it taught.)
 #pragma once
 #include <cstdlib>
 #include <type_traits>
@@ -40,42 +41,7 @@ struct AttnArgs {
     int Lq_alloc; // rows per (batch, head) of q: Lkv, or the compact length of a cache step's queries
     float scale_log2e;
     int xcd_pairs, nq;  // XCD-aware 1-D grid: (batch, head) pairs per XCD and query tiles per pair (0: plain 3-D grid)
-    // attn64 only (attn64_plan): the first n_full workgroups run full passes (256 query rows, `full_per_pair` per (batch,
-    // head) pair, q-blocks [0, 8 * full_per_pair)), the others half passes (128 rows, `half_per_pair` per pair)
-    int n_full, full_per_pair, half_per_pair;
-    // attn4p only — key-split tail (round 5, attn_split_plan below).  Per (batch, head) pair the grid holds `nq_full` full
-    // workgroups (rows q_begin + 128 i, all keys, limited to rows < full_end) and `nq_tail` x `nsplit` split workgroups (rows
-    // tail_begin + 128 j < Lq_rows, key tiles [kt0, kt1) of split s); nsplit == 1: no tail region (nq_tail == 0)
-    int nq_full, nq_tail, nsplit, full_end, tail_begin, pairs;
-    int skip_idle;        // != 0: waves without a single live query row skip the matrix blocks and the soft-max
-    float* part;          // [pair][tail tile][split][wave][66][64] fp32: O (64 registers), m_run, l_run per lane
-    unsigned* counters;   // [pair][tail tile]: splits that have published; the last one combines and resets it to 0
 };
-
-// Key-split of the LAST query tiles of a sequence (round 5).  A batch-1 forward at L = 2438 is 20 query tiles x 32 heads = 640
-// workgroups on 512 slots: one full round + a quarter round that runs one workgroup per CU at 0.58 of a round's time (1.58 rounds
-// for 1.19 of work).  Rows >= r_full (a multiple of 128 x 16: the tiles that fill whole rounds for 32 heads) are therefore cut
-// `nsplit` ways along the KEYS: each split workgroup runs the same online soft-max over its key tiles and publishes (O, m, l) in
-// fp32; the last one to arrive combines them in split order (deterministic) and stores.  The plan is a function of L ALONE — not
-// of the batch, the window or the head count — so a row's arithmetic never depends on what shares its launch (batch invariance,
-// consumed-row window bit-identity: tests/test_gpu_fullsize.py).  nsplit == 1: no split.
-struct AttnSplitPlan { int r_full, nsplit; };
-inline AttnSplitPlan attn_split_plan(int L) {
-    const int nq = (L + QB - 1) / QB, nkt = (L + KB - 1) / KB;
-    const int t_full = nq / 16 * 16, nt = nq - t_full;
-    AttnSplitPlan p{0, 1};
-    if (t_full == 0 || nt == 0) return p;
-    int s = 16 / nt;
-    if (s > 8) s = 8;
-    while (s >= 2 && nkt / s < 4) --s;
-    if (s < 2) return p;
-    p.r_full = t_full * QB;
-    p.nsplit = s;
-    return p;
-}
-constexpr size_t ATTN_SPLIT_HDR = 65536;                       // counters (16 384 of them), at the very start of the workspace
-constexpr size_t ATTN_PART_FLOATS = 4 * 66 * 64;               // one split workgroup's partial
-
 
 // The kernel owns its whole LDS allocation and has no static __shared__ object: the dynamic segment starts at LDS address 0
 // (tests/test_isa.py), so LDS addresses are plain integers — no "base + offset" VALU add per access.
@@ -103,6 +69,3 @@ MM_DEVICE void dma16(const char* sbase, unsigned voff, int lds_byte) {
 }
 
 }  // namespace attn_detail
-
-// attention64.hip
-int launch_attention64(attn_detail::AttnArgs a, int B, hipStream_t s, int var = 0);

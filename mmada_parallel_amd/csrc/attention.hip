@@ -208,46 +208,23 @@ __global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
         // HW_REG_LDS_ALLOC (id 6): LDS_BASE in bits 7:0
         if (__builtin_amdgcn_s_getreg((6) | (0 << 6) | ((8 - 1) << 11)) != 0) __builtin_amdgcn_s_setprio(1);
     }
-    // Workgroup -> (pair, query tile, key split).  1-D grid; with xcd_pairs > 0 XCD-aware (hardware ids round-robin over the 8
-    // XCDs — observed, speed only — so XCD x takes whole (batch, head) pairs: a head's K / vT goes through ONE private L2).
-    // Inside an XCD's share (or the whole grid) every FULL workgroup comes before the first key-split one: the split
-    // workgroups are the short jobs that fill the slots the last full round leaves free.
-    int pair, tile, split = 0;
-    bool tail = false;
-    {
-        const int i = a.xcd_pairs > 0 ? (int)(blockIdx.x >> 3) : (int)blockIdx.x;
-        const int p0 = a.xcd_pairs > 0 ? (int)(blockIdx.x & 7) * a.xcd_pairs : 0;
-        const int np = a.xcd_pairs > 0 ? a.xcd_pairs : a.pairs;
-        const int nf = np * a.nq_full;
-        if (i < nf) {
-            pair = p0 + i / a.nq_full;
-            tile = i - (i / a.nq_full) * a.nq_full;
-        } else {
-            const int per = a.nq_tail * a.nsplit, j = i - nf;
-            pair = p0 + j / per;
-            const int r = j - (j / per) * per;
-            tile = r / a.nsplit;
-            split = r - tile * a.nsplit;
-            tail = true;
-        }
+    int qb, h, b;
+    if (a.xcd_pairs > 0) {
+        const int xcd = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int pair = xcd * a.xcd_pairs + i / a.nq;
+        qb = i - (i / a.nq) * a.nq;
+        b = pair / a.Hq;
+        h = pair - b * a.Hq;
+    } else {
+        qb = blockIdx.x; h = blockIdx.y; b = blockIdx.z;
     }
-    const int b = pair / a.Hq, h = pair - b * a.Hq;
     const int hkv = h / (a.Hq / a.Hkv);
     const bf16_t* Qp = a.q + (size_t)(b * a.Hq + h) * a.Lq_alloc * 128;
     const bf16_t* Kp = a.k + (size_t)(b * a.Hkv + hkv) * a.Lkv * 128;
     const bf16_t* Vp = a.vT + (size_t)(b * a.Hkv + hkv) * 128 * a.Lkv;
 
-    const int row_end = tail ? a.Lq_rows : a.full_end;   // first row this workgroup does NOT own
-    const int q_row = (tail ? a.tail_begin : a.q_begin) + tile * QB + wave * 32 + ql;
+    const int q_row = a.q_begin + qb * QB + wave * 32 + ql;
     const int q_ld = min(q_row, a.Lq_alloc - 1);
-    // key tiles of this workgroup: all of them, or split `split`'s share (the first nkt % nsplit splits take one more)
-    const int nkt = (a.L + KB - 1) / KB;
-    int kt0 = 0, kt1 = nkt;
-    if (tail) {
-        const int base = nkt / a.nsplit, rem = nkt - base * a.nsplit;
-        kt0 = split * base + min(split, rem);
-        kt1 = kt0 + base + (split < rem ? 1 : 0);
-    }
     bf16x8 qf[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) qf[s] = *(const bf16x8*)(Qp + (size_t)q_ld * 128 + s * 16 + hi * 8);
@@ -287,9 +264,10 @@ __global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) vro[j] = TILE_BYTES + ql * 128 + (((2 * j + hi) ^ vsw) << 4);
     }
-    stage(std::integral_constant<int, 0>{}, kt0);
+    const int nkt = (a.L + KB - 1) / KB;
+    stage(std::integral_constant<int, 0>{}, 0);
 
-    auto tile_fn = [&](auto r_, int kt) {
+    auto tile = [&](auto r_, int kt) {
         constexpr int R = decltype(r_)::value, BASE = R * 2 * TILE_BYTES;
         using Next = std::integral_constant<int, R ^ 1>;
         asm volatile("" : "+v"(kro[0]), "+v"(kro[1]), "+v"(kro[2]), "+v"(kro[3]), "+v"(kro[4]), "+v"(kro[5]), "+v"(kro[6]), "+v"(kro[7]));
@@ -297,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
         if constexpr (VAR == 3) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
         A8_SB();
-        const bool more = kt + 1 < kt1;
+        const bool more = kt + 1 < nkt;
         // ---- S^T = K · Q^T ----
         bf16x8 ka[3][2];
 #pragma unroll
@@ -400,66 +378,16 @@ __global__ __launch_bounds__(256, 2) void attn4p_fwd_kernel(AttnArgs a) {
         if (VAR != 2) __builtin_amdgcn_sched_group_barrier(0x008, 4, 1);
         A8_SB();
     };
-    // a wave none of whose 32 query rows exists (the last tile of L = 2438 holds 6 rows) only keeps its share of the K / vT
-    // stream and the tile barriers going: its MFMAs and soft-max would take issue slots and power from the CU's other waves
-    const bool idle = a.skip_idle != 0 && __builtin_amdgcn_readfirstlane(q_row - ql) >= row_end;
-    if (idle) {
-        for (int kt = kt0; kt < kt1; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (kt + 1 < kt1) {
-                if ((kt - kt0) & 1) stage(std::integral_constant<int, 0>{}, kt + 1);
-                else stage(std::integral_constant<int, 1>{}, kt + 1);
-            }
-        }
-    } else {
-        int kt = kt0;
-        for (; kt + 1 < kt1; kt += 2) {
-            tile_fn(std::integral_constant<int, 0>{}, kt);
-            tile_fn(std::integral_constant<int, 1>{}, kt + 1);
-        }
-        if (kt < kt1) tile_fn(std::integral_constant<int, 0>{}, kt);
+    int kt = 0;
+    for (; kt + 1 < nkt; kt += 2) {
+        tile(std::integral_constant<int, 0>{}, kt);
+        tile(std::integral_constant<int, 1>{}, kt + 1);
     }
-
-    if (tail) {
-        // ---- key-split workgroup: publish (O, m, l) of this split; the LAST split to arrive combines all of them ----
-        const int slot_id = pair * a.nq_tail + tile;
-        float* mine = a.part + ((size_t)slot_id * a.nsplit + split) * ATTN_PART_FLOATS + (size_t)wave * (66 * 64) + lane;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mine[(db * 16 + r) * 64] = o[db][r];
-        mine[64 * 64] = m_run;
-        mine[65 * 64] = l_run;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");   // the partials have left this XCD's L2 before the counter moves
-        __syncthreads();                                     // every wave's tile loop is over: the LDS is free
-        volatile unsigned* flag = (volatile unsigned*)lds_at(0);
-        if (tid == 0) *flag = __hip_atomic_fetch_add(a.counters + slot_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (*flag != (unsigned)(a.nsplit - 1)) return;
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (tid == 0) __hip_atomic_store(a.counters + slot_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        const float* base = a.part + (size_t)slot_id * a.nsplit * ATTN_PART_FLOATS + (size_t)wave * (66 * 64) + lane;
-        float m_all = -1e30f;
-        for (int sp = 0; sp < a.nsplit; ++sp) m_all = fmaxf(m_all, base[(size_t)sp * ATTN_PART_FLOATS + 64 * 64]);
-        l_run = 0.f;
-#pragma unroll
-        for (int db = 0; db < 4; ++db)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[db][r] = 0.f;
-        for (int sp = 0; sp < a.nsplit; ++sp) {   // split order: the same sums whichever workgroup arrives last
-            const float* ps = base + (size_t)sp * ATTN_PART_FLOATS;
-            const float w = __builtin_amdgcn_exp2f(ps[64 * 64] - m_all);
-            l_run += ps[65 * 64] * w;
-#pragma unroll
-            for (int db = 0; db < 4; ++db)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[db][r] += ps[(db * 16 + r) * 64] * w;
-        }
-    }
+    if (kt < nkt) tile(std::integral_constant<int, 0>{}, kt);
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (q_row < row_end) {
+    if (q_row < a.Lq_rows) {
         bf16_t* orow = a.out + ((size_t)b * a.out_rows_per_batch + q_row - a.q_begin) * a.ld_out + h * 128;
 #pragma unroll
         for (int db = 0; db < 4; ++db)
@@ -489,38 +417,16 @@ static int attn4p_set_lds_limit() {
 
 static int g_attn_form = -1;  // -1: read MMADA_ATTN_FORM once
 void attention_force_form(int form) { g_attn_form = form; }  // -1: back to MMADA_ATTN_FORM / default  // measurement / test hook: 0 = round-2 issue order, 1 = pipelined matrix blocks
-static int g_attn_split = -1;  // -1: read MMADA_ATTN_SPLIT once (default on); 0: never split the keys of the last query tiles
-void attention_set_split(int on) { g_attn_split = on < 0 ? -1 : (on != 0); }
-static int g_attn_skip_idle = -1;
-void attention_set_skip_idle(int on) { g_attn_skip_idle = on < 0 ? -1 : (on != 0); }
-static bool attn_split_on() {
-    if (g_attn_split < 0) {
-        const char* e = getenv("MMADA_ATTN_SPLIT");
-        g_attn_split = e && e[0] == '0' ? 0 : 1;
-    }
-    return g_attn_split != 0;
-}
-
-// Bytes of the key-split scratch a launch over B sequences of length L with Hq heads may use (counters + fp32 partials);
-// the header alone when the plan does not split this L.
-size_t attention_split_bytes(int B, int Hq, int L) {
-    const AttnSplitPlan p = attn_split_plan(L);
-    if (p.nsplit < 2) return ATTN_SPLIT_HDR;
-    const int lp = (L + 7) / 8 * 8;
-    const int nt = (lp - p.r_full + QB - 1) / QB;
-    return ATTN_SPLIT_HDR + (size_t)B * Hq * nt * p.nsplit * ATTN_PART_FLOATS * sizeof(float);
-}
 
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int B, int Hq, int Hkv, int L,
-                     int Lq_rows, int Lkv, int out_rows_per_batch, int ld_out, hipStream_t s, int q_begin, int Lq_alloc,
-                     void* split_ws, size_t split_ws_bytes) {
+                     int Lq_rows, int Lkv, int out_rows_per_batch, int ld_out, hipStream_t s, int q_begin, int Lq_alloc) {
     if (L <= 0 || B <= 0) return 0;
     if (Lkv % 64 || Lkv < L) return mm_fail("attention: Lkv=%d must be a multiple of 64 and >= L=%d", Lkv, L);
     if (Hq % Hkv) return mm_fail("attention: n_heads %% n_kv_heads != 0");
     if (q_begin < 0 || (q_begin & 31) || q_begin >= Lq_rows) return mm_fail("attention: bad q_begin=%d", q_begin);
     static MmOncePerDevice attr_set;
     MM_ONCE_PER_DEVICE(attr_set, MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT_LDS)));
-    AttnArgs a{};
+    AttnArgs a;
     a.q = q; a.k = k; a.vT = vT; a.out = out;
     a.Hq = Hq; a.Hkv = Hkv; a.L = L; a.Lq_rows = Lq_rows; a.Lkv = Lkv;
     a.out_rows_per_batch = out_rows_per_batch; a.ld_out = ld_out; a.q_begin = q_begin;
@@ -530,24 +436,12 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     const int pairs = Hq * B;
     static const bool xcd_aware = [] { const char* e = getenv("MMADA_ATTN_XCD"); return !(e && e[0] == '0'); }();
     if (g_attn_form < 0) {
-        const char* e = getenv("MMADA_ATTN_FORM");  // 0: round-2 issue order; 1: pipelined matrix blocks; 2: attention64.hip
+        const char* e = getenv("MMADA_ATTN_FORM");  // 0: round-2 issue order; 1: pipelined matrix blocks
         g_attn_form = e ? atoi(e) : 1;
     }
-    // 2: 64 query rows per wave, one wave per SIMD (attention64.hip); 20 + v: its diagnostic variant v (tuning builds)
-    if (g_attn_form == 2 || g_attn_form >= 20) return launch_attention64(a, B, s, g_attn_form == 2 ? 0 : g_attn_form - 20);
+    if (g_attn_form == 2 || g_attn_form >= 20) return mm_fail("attention: form %d (attention64) was removed in round 5", g_attn_form);
     const int nq = (Lq_rows - q_begin + QB - 1) / QB;
-    if (g_attn_form == 0) {   // round-2 kernel: no key split
-        if (xcd_aware && pairs % 8 == 0) {
-            a.xcd_pairs = pairs / 8; a.nq = nq;
-            hipLaunchKernelGGL(attn_fwd_kernel, dim3(nq * pairs), dim3(256), ATT_LDS, s, a);
-        } else {
-            a.xcd_pairs = 0; a.nq = nq;
-            hipLaunchKernelGGL(attn_fwd_kernel, dim3(nq, Hq, B), dim3(256), ATT_LDS, s, a);
-        }
-        MM_CHECK_HIP(hipGetLastError());
-        return 0;
-    }
-    auto fn = attn4p_fwd_kernel<0>;
+    auto fn = g_attn_form == 1 ? attn4p_fwd_kernel<0> : attn_fwd_kernel;
 #ifdef MMADA_TUNE
     switch (g_attn_form) {  // 11-13: diagnostic (wrong results), 14: static priority for the CU's second workgroup
         case 11: fn = attn4p_fwd_kernel<1>; break;
@@ -556,37 +450,17 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
         case 14: fn = attn4p_fwd_kernel<4>; break;
     }
 #endif
-    static MmOncePerDevice attr4;
-    MM_ONCE_PER_DEVICE(attr4, if (attn4p_set_lds_limit()) return 1);
-    // ---- the row / key partition: full workgroups over rows [q_begin, full_end), key-split ones over [tail_begin, Lq_rows) ----
-    if (g_attn_skip_idle < 0) {
-        const char* e = getenv("MMADA_ATTN_SKIP_IDLE");
-        g_attn_skip_idle = e && e[0] == '0' ? 0 : 1;
+    if (g_attn_form != 0) {
+        static MmOncePerDevice attr4;
+        MM_ONCE_PER_DEVICE(attr4, if (attn4p_set_lds_limit()) return 1);
     }
-    a.skip_idle = g_attn_skip_idle;
-    a.pairs = pairs;
-    a.nsplit = 1; a.nq_tail = 0; a.full_end = Lq_rows; a.tail_begin = Lq_rows; a.nq_full = nq;
-    // only when the caller handed in scratch that holds this launch's partials.  (A dLLM-cache step's compact queries follow the
-    // same rule by query index: a step over every token is the plain forward, bit for bit.)
-    const AttnSplitPlan plan = attn_split_plan(L);
-    if (plan.nsplit >= 2 && attn_split_on() && split_ws && Lq_rows > plan.r_full) {
-        const int tail_begin = q_begin > plan.r_full ? q_begin : plan.r_full;
-        const int nq_tail = (Lq_rows - tail_begin + QB - 1) / QB;
-        const size_t need = ATTN_SPLIT_HDR + (size_t)pairs * nq_tail * plan.nsplit * ATTN_PART_FLOATS * sizeof(float);
-        if ((size_t)pairs * nq_tail <= ATTN_SPLIT_HDR / sizeof(unsigned) && need <= split_ws_bytes) {
-            a.nsplit = plan.nsplit; a.nq_tail = nq_tail; a.tail_begin = tail_begin;
-            a.full_end = plan.r_full;
-            a.nq_full = q_begin < plan.r_full ? (plan.r_full - q_begin + QB - 1) / QB : 0;
-            a.counters = (unsigned*)split_ws;
-            a.part = (float*)((char*)split_ws + ATTN_SPLIT_HDR);
-        } else {
-            return mm_fail("attention: key-split scratch too small (%zu bytes given, %zu needed)", split_ws_bytes, need);
-        }
+    if (xcd_aware && pairs % 8 == 0) {
+        a.xcd_pairs = pairs / 8; a.nq = nq;
+        hipLaunchKernelGGL(fn, dim3(nq * pairs), dim3(256), ATT_LDS, s, a);
+    } else {
+        a.xcd_pairs = 0; a.nq = nq;
+        hipLaunchKernelGGL(fn, dim3(nq, Hq, B), dim3(256), ATT_LDS, s, a);
     }
-    const int per_pair = a.nq_full + a.nq_tail * a.nsplit;
-    a.xcd_pairs = (xcd_aware && pairs % 8 == 0) ? pairs / 8 : 0;
-    a.nq = nq;
-    hipLaunchKernelGGL(fn, dim3(per_pair * pairs), dim3(256), ATT_LDS, s, a);
     MM_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -264,18 +264,27 @@ int gemm_plan_code(int M, int N, int K) {
 // 8 zero rows of up to ZERO_ROW_ELEMS / 8 elements per device (never freed: process lifetime): the source of the A rows of
 // the last row tile that lie beyond M
 static int zero_rows_for_device(const bf16_t** out) {
-    static bf16_t* rows[16] = {};
+    static std::atomic<bf16_t*> rows[16];
+    static std::mutex mu;
     static const bool enabled = [] { const char* e = getenv("MMADA_GEMM_ZEROPAD"); return !(e && e[0] == '0'); }();
     *out = nullptr;
     if (!enabled) return 0;
     int dev = 0;
     MM_CHECK_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev >= 16) return 0;
-    if (!rows[dev]) {
-        MM_CHECK_HIP(hipMalloc(&rows[dev], ZERO_ROW_ELEMS * sizeof(bf16_t)));
-        MM_CHECK_HIP(hipMemset(rows[dev], 0, ZERO_ROW_ELEMS * sizeof(bf16_t)));
+    bf16_t* have = rows[dev].load(std::memory_order_acquire);
+    if (!have) {   // normally built by gemm_prepare_device (mmada_create); a bare mmada_gemm_bt call gets here
+        std::lock_guard<std::mutex> lock(mu);
+        have = rows[dev].load(std::memory_order_acquire);
+        if (!have) {
+            bf16_t* p = nullptr;
+            MM_CHECK_HIP(hipMalloc(&p, ZERO_ROW_ELEMS * sizeof(bf16_t)));
+            MM_CHECK_HIP(hipMemset(p, 0, ZERO_ROW_ELEMS * sizeof(bf16_t)));
+            rows[dev].store(p, std::memory_order_release);
+            have = p;
+        }
     }
-    *out = rows[dev];
+    *out = have;
     return 0;
 }
 
@@ -328,6 +337,17 @@ static int silu_lut_for_device(const uint16_t** out, hipStream_t s) {
     *out = have;
     return 0;
 }
+// Everything a GEMM launch would otherwise allocate lazily (the zero rows, the SiLU table: a hipMalloc and a stream
+// synchronise at the FIRST launch on a device) built up front, from mmada_create: a launch then never blocks the host — a
+// tensor-parallel rank group driven by one host thread deadlocks (until the hand-off timeout) if the first SwiGLU launch of the
+// process synchronises rank 0's stream while rank 1's kernels are not enqueued yet.
+int gemm_prepare_device() {
+    const bf16_t* z = nullptr;
+    if (zero_rows_for_device(&z)) return 1;
+    const uint16_t* lut = nullptr;
+    return silu_lut_for_device(&lut, (hipStream_t)0);
+}
+
 void gemm_set_silu_lut(int on) { g_silu_lut.store(on != 0 ? 1 : 0, std::memory_order_relaxed); }
 
 int launch_gemm(int epi, const GemmArgs& g_in, hipStream_t s) {

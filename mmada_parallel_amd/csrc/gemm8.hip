@@ -339,15 +339,28 @@ struct Gemm8 {
                 tile_bal<0, NA0, NA1, 0, SWAP, DROP>(kt);
                 tile_bal<1, NA0, NA1, 0, SWAP, DROP>(kt + 1);
             }
-            tile_bal<0, NA0, NA1, 1, SWAP, DROP>(nk - 2);
-            tile_bal<1, NA0, NA1, 2, SWAP, DROP>(nk - 1);
+            // the two tail K-tiles sit in a loop of ONE trip the compiler cannot count: as straight-line code hipcc picks the
+            // three-address MFMA form there (destination != accumulator), which needs free register tuples the 320-row tile
+            // does not have — 16 extra registers and a spilled accumulator; loop-carried accumulators stay in place
+            int one = 1;
+            asm volatile("" : "+s"(one));
+#pragma nounroll
+            for (int t = 0; t < one; ++t) {
+                tile_bal<0, NA0, NA1, 1, SWAP, DROP>(nk - 2);
+                tile_bal<1, NA0, NA1, 2, SWAP, DROP>(nk - 1);
+            }
         } else {
             for (int kt = 0; kt + 2 < nk; kt += 2) {
                 tile<0, NA0, NA1, 0, SWAP, DROP>(kt);
                 tile<1, NA0, NA1, 0, SWAP, DROP>(kt + 1);
             }
-            tile<0, NA0, NA1, 1, SWAP, DROP>(nk - 2);
-            tile<1, NA0, NA1, 2, SWAP, DROP>(nk - 1);
+            int one = 1;   // see above
+            asm volatile("" : "+s"(one));
+#pragma nounroll
+            for (int t = 0; t < one; ++t) {
+                tile<0, NA0, NA1, 1, SWAP, DROP>(nk - 2);
+                tile<1, NA0, NA1, 2, SWAP, DROP>(nk - 1);
+            }
         }
         if (grp == 0) G8_BARRIER();
     }
@@ -363,7 +376,7 @@ bool short_tiles_on() {
     return g_short_tiles != 0;
 }
 
-int g_tile_order = -1;  // -1: read MMADA_GEMM_TILE_ORDER once; 0: default; GM * 100 + GN
+int g_tile_order = -1;  // -1: read MMADA_GEMM_TILE_ORDER once; 0: per-tile default (launch_cfg8); GM * 100 + GN (GM = 99: all row tiles)
 
 template <int EPI, class G>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {
@@ -432,8 +445,13 @@ int launch_cfg8(const GemmArgs& g, hipStream_t s) {
         const char* e = getenv("MMADA_GEMM_TILE_ORDER");
         g_tile_order = e ? atoi(e) : 0;
     }
-    ga.tile_gm = g_tile_order > 0 ? g_tile_order / 100 : 0;
-    ga.tile_gn = g_tile_order > 0 && g_tile_order % 100 > 0 ? g_tile_order % 100 : 1024 / G::BN;
+    // Default order: per XCD-round of 32 tiles the fabric delivers gm A panels (BM rows each) + gn W panels (BN rows each), gm x gn
+    // = 32, least when gm * BM ~ gn * BN: 4 x 8 for the 320 x 256 tile (FETCH_SIZE -6 % against 8 x 4, gate/up +1.3 % at M = 2440,
+    // every projection +0.6 ... 1.9 % at M = 4880: profiles/r05_tile_order_fetch.txt, r05_block_ab.txt), 8 x 4 bands of 1024
+    // columns for the shorter tiles (there 4 x 8 measured -0.6 ... -2.6 %).  Any order gives the same bits.
+    constexpr int DEF_GM = (G::BM == 320 && G::BN == 256) ? 4 : 0, DEF_GN = (G::BM == 320 && G::BN == 256) ? 8 : 1024 / G::BN;
+    ga.tile_gm = g_tile_order > 0 ? g_tile_order / 100 : DEF_GM;
+    ga.tile_gn = g_tile_order > 0 && g_tile_order % 100 > 0 ? g_tile_order % 100 : DEF_GN;
     hipLaunchKernelGGL(fn, dim3(ntm * ntn), dim3(512), LDS_BYTES, s, ga);
     MM_CHECK_HIP(hipGetLastError());
     return 0;

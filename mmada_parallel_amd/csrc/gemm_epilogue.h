@@ -401,3 +401,5 @@ void gemm8_set_short_tiles(int on);
 void gemm8_set_tile_order(int code);
 // SiLU table of the SwiGLU epilogue (8-phase kernel) on / off; on by default
 void gemm_set_silu_lut(int on);
+// allocate + fill the per-device constants of the GEMM launchers now (zero rows, SiLU table) instead of at the first launch
+int gemm_prepare_device();

@@ -49,8 +49,6 @@ struct mmada_handle {
     bf16_t *x = nullptr, *y = nullptr, *xn = nullptr, *att = nullptr, *hbuf = nullptr, *q = nullptr, *k = nullptr,
            *vT = nullptr, *xg = nullptr;
     int32_t* rows_all = nullptr;
-    void* attn_split = nullptr;   // key-split scratch of the attention kernel (counters at workspace offset 0) and its size
-    size_t attn_split_bytes = 0;
     int32_t* posmap = nullptr;  // [B*Lp] sequence position of every compact stream row (compute-mask forward)
     // dLLM cache: slots, and the one a forward in flight writes its keys / values into (cc != null only inside
     // mmada_forward_cached); cc_pos: position map of a compute-mask step (null: every row is computed)
@@ -111,7 +109,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 static inline int ceil_to(int v, int a) { return (v + a - 1) / a * a; }
 
 struct Carve {
-    size_t split, split_bytes, x, y, xn, att, h, q, k, vT, xg, rows, posmap, total;
+    size_t x, y, xn, att, h, q, k, vT, xg, rows, posmap, total;
     int Lp, Lkv, M;
 };
 
@@ -127,11 +125,6 @@ static Carve carve_for(const mmada_handle* h, int B, int L) {
         off = align_up(off + bytes, 256);
         return o;
     };
-    // scratch of the attention kernel's key split (attention.h): FIRST, so that its counters sit at workspace offset 0 whatever
-    // the shape — mmada_set_workspace zeroes them once, every launch leaves them zero
-    c.split = 0;
-    c.split_bytes = attention_split_bytes(B, h->hq_l, L);
-    take(c.split_bytes);
     // tensor parallel: a row chunk is split into tp equal owner slices of a multiple of 8 rows; the last chunk's slices
     // may reach past M (equal counts for the RCCL reduce-scatter / all-gather), so the stream buffers carry pad rows
     const size_t mrows = (size_t)c.M + (h->cfg.tp_size > 1 ? 8 * h->cfg.tp_size : 0);

@@ -77,14 +77,9 @@ int launch_lfq_gather(const int64_t* idx, void* out, int B, int N, int nbits, in
 
 // attention.hip:  q [B,Hq,Lkv,128], k [B,Hkv,Lkv,128], vT [B,Hkv,128,Lkv] -> out rows (b*Lp_out + l) x (Hq*128)
 // Lq_alloc > 0: q is [B,Hq,Lq_alloc,128] (compact queries against longer cached keys); 0: q shares the keys' Lkv
-// split_ws: scratch of attention_split_bytes(B, Hq, L) bytes whose first 64 KiB were ZERO when handed over the first time (and
-// are zero again after every launch), or null: the key-split of the last query tiles (attention.h: attn_split_plan) is off
 int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t* out, int B, int Hq, int Hkv, int L,
                      int Lq_rows, int Lkv, int out_row_stride_per_batch, int ld_out, hipStream_t s, int q_begin = 0,
-                     int Lq_alloc = 0, void* split_ws = nullptr, size_t split_ws_bytes = 0);
-size_t attention_split_bytes(int B, int Hq, int L);
-void attention_set_split(int on);      // key split of the last query tiles on / off (-1: MMADA_ATTN_SPLIT / default on)
-void attention_set_skip_idle(int on);  // waves without a live query row skip their matrix blocks (-1: default on)
+                     int Lq_alloc = 0);
 
 void attention_force_form(int form);  // 0: round-2 issue order, 1: pipelined matrix blocks (default); tests compare the two
 

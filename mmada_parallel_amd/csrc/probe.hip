@@ -172,3 +172,31 @@ int launch_f2bf_probe(const float* in, bf16_t* out, long long n, hipStream_t s) 
     MM_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+
+// ---- which CUs a stream's CU mask selects (round 5: the tensor-parallel exchange's CU partition, tp_comm.hip) -------------------
+// Every workgroup records where it ran: out[b] = XCC_ID | HW_ID << 8 (HW_REG_XCC_ID bits 3:0; HW_REG_HW_ID: cu_id 11:8, sh_id 12,
+// se_id 15:13).  Launched on a stream created with the given mask; tools/cu_mask_probe.py walks the mask bits.
+__global__ void where_kernel(uint32_t* out) {
+    if (threadIdx.x == 0) {
+        const uint32_t xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11));     // XCC_ID[3:0]
+        const uint32_t hw = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11));      // HW_ID
+        out[blockIdx.x] = (xcc & 15u) | (hw << 8);
+    }
+    __builtin_amdgcn_s_sleep(60);   // stay resident a little: the dispatcher spreads the grid over every allowed CU
+}
+
+extern "C" int mmada_probe_cu_mask(const uint32_t* mask, int words, uint32_t* out_host, int n_blocks) {
+    if (!mask || !out_host || words <= 0 || n_blocks <= 0) return mm_fail("mmada_probe_cu_mask: bad argument");
+    hipStream_t st = nullptr;
+    MM_CHECK_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask));
+    uint32_t* dev = nullptr;
+    MM_CHECK_HIP(hipMalloc(&dev, (size_t)n_blocks * 4));
+    hipLaunchKernelGGL(where_kernel, dim3(n_blocks), dim3(256), 0, st, dev);
+    hipError_t e = hipStreamSynchronize(st);
+    if (e == hipSuccess) e = hipMemcpy(out_host, dev, (size_t)n_blocks * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    (void)hipStreamDestroy(st);
+    if (e != hipSuccess) return mm_fail("mmada_probe_cu_mask: %s", hipGetErrorString(e));
+    return 0;
+}

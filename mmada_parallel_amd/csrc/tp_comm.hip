@@ -21,6 +21,17 @@
 //                  links: the tp-1 pulls of a rank run over tp-1 different links at once (SURVEY.md §5.8 two-shot).
 //   RCCL (mode 2)  ncclReduceScatter / ncclAllGather issued from here (librccl is dlopen'ed: no link-time dependency, the
 //                  host may hand in the library torch already loaded), same owner-side kernel in between.
+//   copy (mode 4)  round 5: the same mapped peer buffers and hand-off counters as pull, but the bytes are moved by the COPY
+//                  ENGINES (hipMemcpyAsync on the mapped peer pointers: SDMA between devices): the tp-1 peer slices of this
+//                  rank's rows into local staging, then the owner kernel reads LOCAL memory only; the all-gather half is
+//                  tp-1 copies and no kernel.  No compute unit waits on a remote load, so nothing of the exchange competes
+//                  with the GEMMs for CUs except the owner kernel (1/tp of the rows, local operands).
+// CU partition (round 5, mmada_comm_set_partition): the 8-phase GEMM's 320x256 tile holds 2 waves x 256 VGPRs per SIMD and
+// 144+ KiB of LDS — while one runs on a CU no exchange wave can be resident there, so "the exchange runs under the next GEMM" was
+// time-slicing at workgroup granularity driven by stream priority.  With a partition the exchange stream is created with a CU
+// mask of `n` CUs (bit i of the mask is CU i / 8 of XCD i % 8: the low n bits spread over all eight XCDs) and the forward's
+// compute kernels run on a library stream masked to the OTHER CUs, joined to the caller's stream by events at both ends:
+// the exchange kernels own their CUs by construction, the GEMMs lose n / 256 of the chip, deterministically.
 // Overlap: the M rows are cut into two chunks; the exchange of chunk i runs on a second (high-priority) stream under the
 // row-parallel GEMM of chunk i+1 / the next column-parallel GEMM of chunk i-1 — also at batch 1, the only join point is
 // the attention (needs every key).
@@ -65,6 +76,7 @@ struct RcclApi {
 struct TpComm {
     int mode = 0;  // 0: buffers allocated, not connected; 1: pull over mapped peer buffers; 2: RCCL;
                    // 3: DIAGNOSTIC "no exchange" (owner-side kernel on this rank's own partial only: wrong values, timing only)
+                   // 4: copy engines over the mapped peer buffers (connected like 1)
     int rank = 0, size = 1, max_rows = 0, d = 0;
     bf16_t* part = nullptr;    // [max_rows + 8*size, d]  published: this rank's partial of the row-parallel GEMM
     bf16_t* hn_pub = nullptr;  // [max_rows + 8*size, d]  published: normalised rows this rank owns (at their global row)
@@ -79,6 +91,11 @@ struct TpComm {
     TpPeers peers{};
     void* opened[4][TP_MAX] = {};
     hipStream_t sc = nullptr;  // exchange stream
+    hipStream_t s_cmp = nullptr;  // CU partition: compute stream masked to the CUs the exchange stream does not own (else null)
+    int part_cus = 0;             // CUs of the exchange stream's mask (0: no partition)
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    bf16_t* stage = nullptr;   // copy transport: [size][ceil(max_rows / size) + 16, d] peer slices of this rank's rows
+    size_t stage_stride = 0;   // elements per peer
     hipEvent_t ev_g[2] = {}, ev_c[2] = {};
     int chunks = 2;
     long long timeout = 0;     // hand-off timeout in wall_clock64 ticks (100 MHz)
@@ -375,6 +392,38 @@ int exchange(mmada_handle* h, const Slice& sl, const bf16_t* norm_w, hipStream_t
         MM_CHECK_HIP(hipGetLastError());
         return 0;
     }
+    if (c->mode == 4) {
+        if (signal_wait(c, s)) return 1;  // every rank's partial of this chunk is complete
+        // the tp - 1 peer slices of MY rows -> local staging, by the copy engines; the kernel then sums local operands.  The
+        // source pointer of peer j is shifted so that the kernel's row index m addresses staging row m - r0.
+        ReduceArgs b = a;
+        b.nsrc = c->size;
+        if (own > 0) {
+            for (int j = 0; j < c->size; ++j) {
+                if (j == c->rank) { b.p.part[j] = c->part; continue; }
+                bf16_t* dst = c->stage + (size_t)j * c->stage_stride;
+                MM_CHECK_HIP(hipMemcpyAsync(dst, c->peers.part[j] + (size_t)sl.r0 * d, (size_t)own * d * 2, hipMemcpyDefault, s));
+                b.p.part[j] = dst - (size_t)sl.r0 * d;
+            }
+            const dim3 grid((own + 3) / 4), blk(256);
+            switch (c->size) {
+                case 2: hipLaunchKernelGGL(tp_reduce_norm_kernel<2>, grid, blk, 0, s, b); break;
+                case 4: hipLaunchKernelGGL(tp_reduce_norm_kernel<4>, grid, blk, 0, s, b); break;
+                case 8: hipLaunchKernelGGL(tp_reduce_norm_kernel<8>, grid, blk, 0, s, b); break;
+                default: hipLaunchKernelGGL(tp_reduce_norm_kernel<0>, grid, blk, 0, s, b);
+            }
+            MM_CHECK_HIP(hipGetLastError());
+        }
+        if (signal_wait(c, s)) return 1;  // every owner's normalised rows are published
+        for (int j = 0; j < c->size; ++j) {   // all-gather half: tp - 1 copies, no kernel
+            if (j == c->rank) continue;
+            const int j0 = min(sl.m1, sl.m0 + j * sl.slice), j1 = min(sl.m1, j0 + sl.slice);
+            if (j1 > j0)
+                MM_CHECK_HIP(hipMemcpyAsync(h->xn + (size_t)j0 * d, c->peers.hn[j] + (size_t)j0 * d, (size_t)(j1 - j0) * d * 2,
+                                            hipMemcpyDefault, s));
+        }
+        return 0;
+    }
     if (c->mode == 3) {  // diagnostic: the forward without its exchange (bench.py: exposed exchange time = real - this)
         a.nsrc = 1; a.presum = c->part + (size_t)sl.r0 * d;
         if (own > 0) hipLaunchKernelGGL(tp_reduce_norm_kernel<0>, dim3((own + 3) / 4), dim3(256), 0, s, a);
@@ -429,9 +478,23 @@ struct CommExport {  // what a rank hands its peers (mmada_comm_create -> mmada_
 // ---- forward ---------------------------------------------------------------------------------------------------------
 // All blocks of a tensor-parallel forward.  h->x holds the embeddings (replicated), every rank keeps its own rows of the
 // residual stream from here on.  Compute on `s`, exchanges on the library's second stream.
-int tp_forward_body(mmada_handle* h, hipStream_t s) {
+static int tp_forward_body_on(mmada_handle* h, hipStream_t s);
+
+int tp_forward_body(mmada_handle* h, hipStream_t s_user) {
     TpComm* c = h->tp;
     if (!c || c->mode == 0) return mm_fail("tensor-parallel forward: no transport connected (mmada_comm_create + connect)");
+    if (!c->s_cmp) return tp_forward_body_on(h, s_user);
+    // CU partition: the blocks run on the library's masked compute stream, forked from and joined to the caller's stream
+    MM_CHECK_HIP(hipEventRecord(c->ev_in, s_user));
+    MM_CHECK_HIP(hipStreamWaitEvent(c->s_cmp, c->ev_in, 0));
+    const int rc = tp_forward_body_on(h, c->s_cmp);
+    MM_CHECK_HIP(hipEventRecord(c->ev_out, c->s_cmp));
+    MM_CHECK_HIP(hipStreamWaitEvent(s_user, c->ev_out, 0));
+    return rc;
+}
+
+static int tp_forward_body_on(mmada_handle* h, hipStream_t s) {
+    TpComm* c = h->tp;
     if (h->M > c->max_rows) return mm_fail("tensor-parallel forward: %d rows exceed the comm buffers (%d)", h->M, c->max_rows);
     const int d = h->cfg.d_model, tp = c->size, M = h->M, nl = h->cfg.n_layers;
     if ((d >> 3) > 64 * MAXCH) return mm_fail("tensor-parallel forward: d_model > %d is not supported", 64 * MAXCH * 8);
@@ -475,14 +538,14 @@ int tp_forward_body(mmada_handle* h, hipStream_t s) {
         {   // ---- attention over this rank's heads: the one join point (every key of a sequence) ----
             ProfScope p(h, layer, 1, 4.0 * h->hq_l * (double)h->B * h->L * h->L * 128.0, s);
             if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->Lp, h->Lkv, h->Lp,
-                                 h->hq_l * 128, s, 0, 0, h->attn_split, h->attn_split_bytes)) return 1;
+                                 h->hq_l * 128, s)) return 1;
         }
         // ---- attn_out (row-parallel) chunk by chunk; chunk k's exchange runs under chunk k+1's GEMM ----
         for (int k = 0; k < nch; ++k) {
             GemmArgs o{};
             o.A = h->att + (size_t)sl[k].m0 * h->hq_l * 128; o.W = lw.wo; o.C = c->part + (size_t)sl[k].m0 * d;
             o.M = sl[k].m1 - sl[k].m0; o.N = d; o.K = h->hq_l * 128;
-            o.lda = o.K; o.ldw = o.K; o.ldc = d; o.publish = c->mode == 1;
+            o.lda = o.K; o.ldw = o.K; o.ldc = d; o.publish = c->mode == 1 || c->mode == 4;
             {
                 ProfScope p(h, layer, 2, 2.0 * o.M * rows_real * o.N * o.K, s);
                 if (launch_gemm(EPI_STORE, o, s)) return 1;
@@ -504,7 +567,7 @@ int tp_forward_body(mmada_handle* h, hipStream_t s) {
             GemmArgs o{};
             o.A = h->hbuf + (size_t)sl[k].m0 * h->f_l; o.W = lw.wdown; o.C = c->part + (size_t)sl[k].m0 * d;
             o.M = sl[k].m1 - sl[k].m0; o.N = d; o.K = h->f_l;
-            o.lda = h->f_l; o.ldw = h->f_l; o.ldc = d; o.publish = c->mode == 1;
+            o.lda = h->f_l; o.ldw = h->f_l; o.ldc = d; o.publish = c->mode == 1 || c->mode == 4;
             {
                 ProfScope p(h, layer, 4, 2.0 * o.M * rows_real * o.N * o.K, s);
                 if (launch_gemm(EPI_STORE, o, s)) return 1;
@@ -531,7 +594,7 @@ int tp_gather_stream(mmada_handle* h, bf16_t* full_out, hipStream_t s) {
             hipLaunchKernelGGL(copy_rows_kernel, dim3((own + 3) / 4), dim3(256), 0, s, h->x, c->hn_pub, sl.r0, sl.r1, d);
             hipLaunchKernelGGL(copy_rows_kernel, dim3((own + 3) / 4), dim3(256), 0, s, h->x, full_out, sl.r0, sl.r1, d);
         }
-        if (c->mode == 1) {
+        if (c->mode == 1 || c->mode == 4) {
             if (signal_wait(c, s)) return 1;
             hipLaunchKernelGGL(tp_gather_kernel, dim3((sl.m1 - sl.m0 + 3) / 4), dim3(256), 0, s, c->peers, c->rank, sl.m0,
                                sl.m1, sl.slice, d, full_out, 0);
@@ -560,6 +623,10 @@ void tp_comm_free(mmada_handle* h) {
         if (c->ev_c[k]) (void)hipEventDestroy(c->ev_c[k]);
     }
     if (c->sc) (void)hipStreamDestroy(c->sc);
+    if (c->s_cmp) (void)hipStreamDestroy(c->s_cmp);
+    if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+    if (c->ev_out) (void)hipEventDestroy(c->ev_out);
+    (void)hipFree(c->stage);
     (void)hipFree(c->part); (void)hipFree(c->hn_pub); (void)hipFree(c->ctr);
     (void)hipFree(c->rs_tmp); (void)hipFree(c->stats_pub); (void)hipFree(c->stats_all); (void)hipFree(c->head_buf);
     delete c;
@@ -612,6 +679,10 @@ int mmada_comm_create(mmada_handle* h, int max_rows, void* export_out) {
     c->err = (int*)(c->ctr + 128);
     c->data_fine = fine_data;
     MM_CHECK_HIP(hipMalloc(&c->rs_tmp, ((size_t)(max_rows + c->size - 1) / c->size + 16) * c->d * 2));
+    c->stage_stride = ((size_t)(max_rows + c->size - 1) / c->size + 16) * c->d;   // one owner slice of the largest chunk
+    MM_CHECK_HIP(hipMalloc(&c->stage, c->stage_stride * c->size * 2));
+    MM_CHECK_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    MM_CHECK_HIP(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
     MM_CHECK_HIP(alloc_pub((void**)&c->stats_pub, (size_t)STAT_ROWS * sizeof(TextStat), true, nullptr));
     MM_CHECK_HIP(hipMemset(c->stats_pub, 0, (size_t)STAT_ROWS * sizeof(TextStat)));
     MM_CHECK_HIP(hipMalloc(&c->stats_all, (size_t)c->size * STAT_ROWS * sizeof(TextStat)));
@@ -742,7 +813,8 @@ int mmada_comm_set_mode(mmada_handle* h, int mode) {
     if (mode == 1 && !c->peers.ctr[other]) return mm_fail("mmada_comm_set_mode: the pull transport was never connected");
     if (mode == 2 && !c->comm) return mm_fail("mmada_comm_set_mode: the RCCL transport was never connected");
     if (mode == 3 && c->mode == 0) return mm_fail("mmada_comm_set_mode: connect a transport before the no-exchange diagnostic");
-    if (mode < 1 || mode > 3) return mm_fail("mmada_comm_set_mode: mode must be 1 (pull), 2 (RCCL) or 3 (diagnostic: no exchange)");
+    if (mode == 4 && !c->peers.ctr[other]) return mm_fail("mmada_comm_set_mode: the copy transport needs the mapped peer buffers (connect_ipc / connect_local)");
+    if (mode < 1 || mode > 4) return mm_fail("mmada_comm_set_mode: mode must be 1 (pull), 2 (RCCL), 3 (diagnostic: no exchange) or 4 (copy engines)");
     c->mode = mode;
     return 0;
 }
@@ -755,6 +827,44 @@ int mmada_comm_rccl_nranks(mmada_handle* h) {
     return h->tp->size;  // a librccl without ncclCommCount: the size the communicator was initialised with
 }
 
+/* CU partition of the exchange (see the header comment): exchange_cus = 0 removes it; else the exchange stream is re-created on
+ * `exchange_cus` CUs (a multiple of 8: the same number on every XCD) and the forward's compute kernels run on a library stream
+ * masked to the remaining CUs.  Call between forwards (synchronises the device). */
+int mmada_comm_set_partition(mmada_handle* h, int exchange_cus) {
+    if (!h || !h->tp) return mm_fail("mmada_comm_set_partition: no comm");
+    TpComm* c = h->tp;
+    int dev = 0, ncu = 0;
+    MM_CHECK_HIP(hipGetDevice(&dev));
+    MM_CHECK_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (exchange_cus < 0 || exchange_cus % 8 || exchange_cus >= ncu)
+        return mm_fail("mmada_comm_set_partition: exchange_cus=%d must be a multiple of 8 below the device's %d CUs", exchange_cus, ncu);
+    MM_CHECK_HIP(hipDeviceSynchronize());
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (c->s_cmp) { (void)hipStreamDestroy(c->s_cmp); c->s_cmp = nullptr; }
+    if (c->sc) { (void)hipStreamDestroy(c->sc); c->sc = nullptr; }
+    c->part_cus = exchange_cus;
+    if (exchange_cus == 0) {
+        MM_CHECK_HIP(hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, hi));
+        return 0;
+    }
+    const int words = (ncu + 31) / 32;
+    uint32_t mx[16] = {}, mc[16] = {};
+    if (words > 16) return mm_fail("mmada_comm_set_partition: %d CUs exceed the mask buffer", ncu);
+    for (int i = 0; i < ncu; ++i) (i < exchange_cus ? mx : mc)[i / 32] |= 1u << (i % 32);
+    MM_CHECK_HIP(hipExtStreamCreateWithCUMask(&c->sc, words, mx));
+    MM_CHECK_HIP(hipExtStreamCreateWithCUMask(&c->s_cmp, words, mc));
+    return 0;
+}
+int mmada_comm_partition(mmada_handle* h) { return h && h->tp ? h->tp->part_cus : 0; }
+/* The library's exchange stream and (with a partition) masked compute stream, for probes that time kernels on them. */
+int mmada_comm_streams(mmada_handle* h, void** exchange_out, void** compute_out) {
+    if (!h || !h->tp) return mm_fail("mmada_comm_streams: no comm");
+    if (exchange_out) *exchange_out = (void*)h->tp->sc;
+    if (compute_out) *compute_out = (void*)h->tp->s_cmp;
+    return 0;
+}
+
 void* mmada_comm_part_ptr(mmada_handle* h) { return h && h->tp ? (void*)h->tp->part : nullptr; }
 
 /* One exchange over every row of the resident (B, L) carve, for probes and self-tests: the caller filled the partial
@@ -764,7 +874,7 @@ int mmada_comm_exchange(mmada_handle* h, const void* norm_w, void* stream) {
     if (!h || !h->tp || h->M == 0 || !norm_w) return mm_fail("mmada_comm_exchange: need a comm and a resident carve (mmada_embed)");
     const Slice sl = chunk_slice(h->M, h->tp->size, h->tp->rank, 1, 0);
     h->xn_is_layer0 = false;  // xn is about to be overwritten
-    if (h->tp->mode == 1) hipLaunchKernelGGL(tp_flush_kernel, dim3(256), dim3(64), 0, (hipStream_t)stream);
+    if (h->tp->mode == 1 || h->tp->mode == 4) hipLaunchKernelGGL(tp_flush_kernel, dim3(256), dim3(64), 0, (hipStream_t)stream);
     return exchange(h, sl, (const bf16_t*)norm_w, (hipStream_t)stream);
 }
 
@@ -805,7 +915,7 @@ int mmada_text_select_tp(mmada_handle* h, const int32_t* rows, int B, int T, int
         return 1;
     double* conf = (double*)scratch;
     int32_t* x0 = (int32_t*)((char*)scratch + (size_t)R * 8);
-    if (c->mode == 1) {
+    if (c->mode == 1 || c->mode == 4) {
         if (signal_wait(c, s)) return 1;
         hipLaunchKernelGGL(tp_text_combine_kernel, dim3((R + 255) / 256), dim3(256), 0, s, c->peers, c->size, c->rank,
                            c->stats_pub, (const TextStat*)nullptr, 0, R, conf, x0);

@@ -386,7 +386,7 @@ class LLaDAForMultiModalGeneration:
         mode, err, fine = C.c_int(), C.c_int(), C.c_int()
         abi.check(self._lib.mmada_comm_status(self._handle, C.byref(mode), C.byref(err), C.byref(fine), abi.stream_ptr()),
                   "mmada_comm_status")
-        return {"mode": {0: "none", 1: "pull", 2: "rccl", 3: "no-exchange diagnostic"}[mode.value], "error": err.value, "finegrained_counters": bool(fine.value & 1),
+        return {"mode": {0: "none", 1: "pull", 2: "rccl", 3: "no-exchange diagnostic", 4: "copy"}[mode.value], "error": err.value, "finegrained_counters": bool(fine.value & 1),
                 "finegrained_buffers": bool(fine.value & 2)}
 
     def comm_selftest(self, iters: int = 3, L: int = 96) -> bool:
@@ -427,8 +427,10 @@ class LLaDAForMultiModalGeneration:
     def init_tp_comm(self, max_batch: int, max_len: int, group=None, transport: str = "auto") -> str:
         """Connect the library's tensor-parallel exchange over the ranks of `group` (a torch.distributed group: control
         plane only — handles / unique id are exchanged as objects; the data path never goes through torch).
-        transport: "pull" (mapped peer buffers, hipIpc), "rccl", or "auto" = pull if it connects AND passes the self-test
-        on every rank, else RCCL, else the host-issued all-reduce of the segment API.  Returns what is in use."""
+        transport: "pull" (mapped peer buffers, hipIpc), "copy" (the same mapped buffers, bytes moved by the copy engines),
+        "rccl", or "auto" = pull if it connects AND passes the self-test on every rank, else RCCL, else the host-issued
+        all-reduce of the segment API.  Returns what is in use.  MMADA_TP_EXCHANGE_CUS=n (a multiple of 8) additionally gives
+        the exchange stream n CUs of its own and masks the compute stream to the rest (mmada_comm_set_partition)."""
         import torch.distributed as dist
 
         lib = self._lib
@@ -446,21 +448,23 @@ class LLaDAForMultiModalGeneration:
             return all(got)
 
         chosen = None
-        if transport in ("auto", "pull"):
+        if transport in ("auto", "pull", "copy"):
             blobs = [None] * self.tp_size
             dist.all_gather_object(blobs, buf.raw if exported else None, group=group)
             ok = exported and all(b is not None for b in blobs)
             if ok:
                 ok = lib.mmada_comm_connect_ipc(self._handle, b"".join(blobs)) == 0
             ok = all_agree(ok)
+            if ok and transport == "copy":
+                ok = all_agree(lib.mmada_comm_set_mode(self._handle, 4) == 0)
             if ok:
                 self._comm_in_library = True
                 lib.mmada_comm_set_timeout(self._handle, 3.0)   # a transport that cannot work is abandoned quickly
                 ok = all_agree(self.comm_selftest())
                 lib.mmada_comm_set_timeout(self._handle, 0.0)   # back to MMADA_TP_TIMEOUT_S; clears a sticky error
             if ok:
-                chosen = "pull"
-            elif transport == "pull":
+                chosen = "copy" if transport == "copy" else "pull"
+            elif transport in ("pull", "copy"):
                 raise abi.MmadaError("tensor-parallel pull transport failed to connect or failed its self-test: "
                                      + (lib.mmada_last_error() or b"").decode())
         if chosen is None and transport in ("auto", "rccl"):
@@ -501,7 +505,14 @@ class LLaDAForMultiModalGeneration:
                         lib.mmada_comm_set_mode(self._handle, 1)                         # the forward keeps the pull transport
                     self._rccl_also = all_agree(ok)
         self.tp_collective = chosen
+        cus = int(os.environ.get("MMADA_TP_EXCHANGE_CUS", "0") or 0)
+        if cus and self._comm_in_library:
+            abi.check(lib.mmada_comm_set_partition(self._handle, cus), "mmada_comm_set_partition")
         return chosen
+
+    def set_exchange_partition(self, exchange_cus: int) -> None:
+        """Give the exchange stream `exchange_cus` CUs of its own (0: none) — mmada_comm_set_partition."""
+        abi.check(self._lib.mmada_comm_set_partition(self._handle, int(exchange_cus)), "mmada_comm_set_partition")
 
     def collective_probe(self, L: int, B: int = 1, iters: int = 10):
         """Outside any timed region: one exchange (reduce-scatter + RMSNorm + all-gather of B*L rows x d bf16) timed alone,
@@ -559,7 +570,7 @@ class LLaDAForMultiModalGeneration:
 
         import torch.distributed as dist
 
-        real_mode = {"pull": 1, "rccl": 2}[self.tp_collective]
+        real_mode = {"pull": 1, "rccl": 2, "copy": 4}[self.tp_collective]
 
         def timed(mode):
             abi.check(self._lib.mmada_comm_set_mode(self._handle, mode), "mmada_comm_set_mode")
@@ -597,7 +608,8 @@ class LLaDAForMultiModalGeneration:
         # RCCL's reduce-scatter / all-gather would be captured on a forked stream; whether every call it makes is
         # capturable has never been exercised with more than one rank, so only the pull transport (plain kernels and
         # device-memory counters) qualifies under tensor parallelism
-        return self.tp_size == 1 or (getattr(self, "_comm_in_library", False) and getattr(self, "tp_collective", None) == "pull")
+        return self.tp_size == 1 or (getattr(self, "_comm_in_library", False) and getattr(self, "tp_collective", None) in ("pull", "copy")
+                                     and self._lib.mmada_comm_partition(self._handle) == 0)   # a CU mask does not survive capture
 
     # ---- dLLM cache (model/modeling_llada.py:593-600,929-940,1244-1245,1406-1426) ----------------------------------------
     def caching(self, enable: bool = True):

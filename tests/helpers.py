@@ -269,7 +269,7 @@ def paint_util_image():
 _TP_STREAMS = []
 
 
-def tp_group(cfg_base, sd, tp, max_rows, dev="cuda:0"):
+def tp_group(cfg_base, sd, tp, max_rows, dev="cuda:0", transport="pull", exchange_cus=0):
     """The ranks of a tensor-parallel group as separate handles of ONE process, each on its own stream, connected with
     mmada_comm_connect_local (tests/test_gpu_tp.py explains why this is the multi-device code path unchanged)."""
     import ctypes as C
@@ -285,7 +285,11 @@ def tp_group(cfg_base, sd, tp, max_rows, dev="cuda:0"):
     arr = (C.c_void_p * tp)(*[m._handle.value for m in ranks])
     for m in ranks:
         abi.check(lib.mmada_comm_connect_local(m._handle, arr), "connect_local")
-        m._comm_in_library, m.tp_collective = True, "pull"
+        m._comm_in_library, m.tp_collective = True, transport
+        if transport == "copy":   # the same mapped buffers, bytes moved by the copy engines (csrc/tp_comm.hip mode 4)
+            abi.check(lib.mmada_comm_set_mode(m._handle, 4), "set_mode")
+        if exchange_cus:
+            abi.check(lib.mmada_comm_set_partition(m._handle, exchange_cus), "set_partition")
     # One pool of compute streams for every group this process ever builds: a rank's wait kernel spins until its peers'
     # launches run, so no two live streams may share a hardware queue (GPU_MAX_HW_QUEUES, tests/conftest.py) — fresh
     # streams per group would walk through the queues and end up doubling up (seen as hand-off timeouts, status.error).

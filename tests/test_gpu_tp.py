@@ -25,8 +25,12 @@ os.environ.setdefault("MMADA_TP_TIMEOUT_S", "8")
 _group, _each = tp_group, tp_each
 
 
-@pytest.mark.parametrize("chunks", ["2", "1"])
-def test_exchange_and_forward_tp2_in_one_process(tiny_tp1, chunks, monkeypatch):
+@pytest.mark.parametrize("chunks,transport,cus", [("2", "pull", 0), ("1", "pull", 0), ("2", "copy", 0), ("1", "copy", 0)])
+def test_exchange_and_forward_tp2_in_one_process(tiny_tp1, chunks, transport, cus, monkeypatch):
+    """transport "copy": the bytes move by hipMemcpyAsync (copy engines) into local staging, the owner kernel reads local memory
+    only.  Same protocol, same arithmetic: it must produce the bits of the pull transport.  (The CU partition,
+    mmada_comm_set_partition, is exercised on a one-rank group below: two in-process ranks with two CU-masked queues each
+    outgrow the hardware queues one process gets, and a rank's spinning wait kernel then blocks its peer's launches.)"""
     monkeypatch.setenv("MMADA_TP_CHUNKS", chunks)
     tp = 2
     job = tiny_job()
@@ -35,9 +39,10 @@ def test_exchange_and_forward_tp2_in_one_process(tiny_tp1, chunks, monkeypatch):
     ids[2, :4] = torch.arange(7, 11, device=DEV)
     B, L = ids.shape
     Lp = (L + 7) // 8 * 8
-    ranks, streams = _group(synth.CFG_TINY, tiny_sd(), tp, B * Lp)
+    ranks, streams = _group(synth.CFG_TINY, tiny_sd(), tp, B * Lp, transport=transport, exchange_cus=cus)
     d = synth.CFG_TINY["d_model"]
     lib = ranks[0]._lib
+    assert ranks[0].comm_status()["mode"] == transport and lib.mmada_comm_partition(ranks[0]._handle) == cus
 
     # ---- one exchange on known data: every rank's normalised rows must equal the expectation bit for bit ----
     M = B * Lp
@@ -80,7 +85,12 @@ def test_exchange_and_forward_tp2_in_one_process(tiny_tp1, chunks, monkeypatch):
     mean = ((hid[0].float() - ref).abs().mean() / ref.abs().mean()).item()
     lr = tiny_tp1.head_rows(rows, synth.TEXT_VOCAB, synth.TEXT_VOCAB + 512).float()
     lerr = ((lg[0].float() - lr).abs().max() / lr.abs().max()).item()
-    print(f"TP=2 (library exchange, chunks={chunks}) vs TP=1: hidden max rel {err:.3e} mean rel {mean:.3e}; logits max rel {lerr:.3e}")
+    if transport != "pull" or cus:   # against the plain pull transport on the same inputs: bit for bit
+        base, bstreams = _group(synth.CFG_TINY, tiny_sd(), tp, B * Lp)
+        _each(base, bstreams, lambda m: m.forward_body(ids))
+        bh = _each(base, bstreams, lambda m: m.hidden_state())
+        assert torch.equal(bh[0], hid[0]), f"{transport}, {cus} exchange CUs: differs from the pull transport"
+    print(f"TP=2 (library exchange, chunks={chunks}, {transport}, {cus} exchange CUs) vs TP=1: hidden max rel {err:.3e} mean rel {mean:.3e}; logits max rel {lerr:.3e}")
     # every rank rounds its partial to bf16 before the (fp32, rank-ordered) sum, and partials are larger than their sum:
     # measured on MI355X: max 1.5e-2, mean 3.9e-3 of the stream's magnitude (TP=1 vs the oracle: 1.0e-2 / 6e-4)
     assert err < 2.5e-2 and mean < 6.0e-3 and lerr < 2.5e-2
@@ -168,8 +178,8 @@ def tiny_tp1():
     return LLaDAForMultiModalGeneration.from_state_dict(synth.full_config(synth.CFG_TINY), tiny_sd(), device=DEV)
 
 
-@pytest.mark.parametrize("transport", ["rccl", "pull"])
-def test_single_rank_group_runs_the_whole_transport_and_equals_the_plain_forward(tiny_tp1, transport):
+@pytest.mark.parametrize("transport,cus", [("rccl", 0), ("pull", 0), ("copy", 0), ("pull", 16), ("rccl", 32)])
+def test_single_rank_group_runs_the_whole_transport_and_equals_the_plain_forward(tiny_tp1, transport, cus):
     """Round-4 review: the RCCL transport (ncclReduceScatter -> owner kernel -> ncclAllGather, csrc/tp_comm.hip mode 2) had never
     executed a collective — RCCL refuses two ranks on one device and no multi-GPU box is available to the tests.  A ONE-rank
     communicator runs every line of it: the dlopen'ed symbol table, ncclCommInitRank, the datatype / count / offset arithmetic
@@ -177,7 +187,9 @@ def test_single_rank_group_runs_the_whole_transport_and_equals_the_plain_forward
     exchange stream and event joins, the all-gather read-out of the residual stream and the vocabulary-parallel text head
     (one slice = the whole vocabulary).  With one rank there is no second partial to round, so the result must equal the plain
     forward BIT FOR BIT; the exchange self-test compares with the local expectation.  The same for the pull transport with
-    no peer (hand-off kernels, the run-time-size reduce kernel)."""
+    no peer (hand-off kernels, the run-time-size reduce kernel), for the copy-engine transport, and with a CU PARTITION (cus > 0:
+    the exchange stream owns `cus` CUs, the forward's compute kernels run on the library's stream masked to the others, forked
+    from and joined to the caller's stream: mmada_comm_set_partition)."""
     from mmada_parallel_amd import LLaDAForMultiModalGeneration
 
     lib = abi.lib()
@@ -207,6 +219,11 @@ def test_single_rank_group_runs_the_whole_transport_and_equals_the_plain_forward
         else:
             arr = (C.c_void_p * 1)(m._handle.value)
             abi.check(lib.mmada_comm_connect_local(m._handle, arr), "connect_local")
+            if transport == "copy":
+                abi.check(lib.mmada_comm_set_mode(m._handle, 4), "set_mode")
+        if cus:
+            abi.check(lib.mmada_comm_set_partition(m._handle, cus), "set_partition")
+        assert lib.mmada_comm_partition(m._handle) == cus
         m._comm_in_library, m.tp_collective = True, transport
         assert m.comm_status()["mode"] == transport
         assert m.comm_selftest(iters=3, L=96), "exchange self-test (known partials vs the local expectation)"
@@ -245,10 +262,10 @@ def test_single_rank_group_runs_the_whole_transport_and_equals_the_plain_forward
         abi.check(lib.mmada_comm_set_mode(m._handle, 3), "set_mode")
         with pytest.raises(abi.MmadaError):
             check_tp_exchange(m)
-        abi.check(lib.mmada_comm_set_mode(m._handle, 2 if transport == "rccl" else 1), "set_mode")
+        abi.check(lib.mmada_comm_set_mode(m._handle, {"rccl": 2, "pull": 1, "copy": 4}[transport]), "set_mode")
         from helpers import save_parity
 
-        save_parity(f"single_rank_{transport}_transport", {"bit_identical_to_plain_forward": True, "rccl_nranks": int(lib.mmada_comm_rccl_nranks(m._handle)),
+        save_parity(f"single_rank_{transport}_transport" + (f"_{cus}_exchange_cus" if cus else ""), {"bit_identical_to_plain_forward": True, "rccl_nranks": int(lib.mmada_comm_rccl_nranks(m._handle)),
                                                           "selftest": True, "vocab_parallel_head_equals_replicated": True})
     finally:
         lib.mmada_set_option(b"tp_allow_single_rank", 0)

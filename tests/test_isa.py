@@ -35,24 +35,3 @@ def test_tp_pull_transport_uses_16_byte_system_scope_loads():
     report, errors = isa_check.check_tp_pull()
     assert not errors, "\n".join(errors)
     assert {r[0].split("ILi")[-1][:1] for r in report if "reduce" in r[0]} >= {"2", "4", "8"}
-
-
-def test_attention64_owns_its_accumulator_file():
-    """csrc/attention64.hip keeps O and Q in a[0:191] by hand (every MFMA is an asm statement): the compiled kernel must have
-    no spill and no scratch, no compiler-issued instruction may touch a[0:191] (the compiler parks values in a[192:255] under
-    register pressure — fine), and no VALU may write an MFMA's VGPR operand within two wait states of the MFMA (hipcc pads
-    that hazard only for MFMAs it emits itself; the un-padded steady-state tiles rely on this check)."""
-    import attn64_audit
-
-    s = attn64_audit.compile_s()
-    meta, problems, k = attn64_audit.audit(s)
-    assert not problems, problems
-    assert not attn64_audit.mfma_operand_hazards(k)
-    import isa_check
-    assert not isa_check.check_m0("attn64_fwd_kernel", k.split("\n"))   # the asm LDS-DMA statements own M0
-    import re
-    counted = len(re.findall(r"s_waitcnt lgkmcnt\([1-9]\d*\)", k))
-    assert counted >= 60, f"{counted} counted LDS waits: the compiler drains the queue in front of the asm MFMAs again"
-    assert meta["vgpr_spill_count"] == 0 and meta["private_segment_fixed_size"] == 0
-    hot = [g for g in attn64_audit.gaps(k) if g[0] == 64 and g[1] < 3000]
-    assert len(hot) >= 2, "the two steady-state key tiles (64 MFMAs each) of a full pass"

@@ -76,9 +76,8 @@ def main():
             torch.cuda.synchronize()
             ms[form].append(e0.elapsed_time(e1) / args.iters)
     lib.mmada_set_option(b"attention_form", -1)
-    names = {0: "round-2 issue order", 1: "pipelined matrix blocks", 2: "attention64: 64 rows per wave, one wave per SIMD", 11: "DIAG no soft-max", 12: "DIAG no MFMA", 13: "DIAG no barrier",
-             14: "static priority, second workgroup", 21: "attn64 DIAG no LDS-DMA", 22: "attn64 DIAG no exponentials",
-             24: "attn64 DIAG no fragment reads", 28: "attn64 DIAG no MFMA", 27: "attn64 DIAG MFMAs only", 34: "attn64 DIAG LDS-DMA only"}
+    names = {0: "round-2 issue order", 1: "pipelined matrix blocks", 11: "DIAG no soft-max", 12: "DIAG no MFMA", 13: "DIAG no barrier",
+             14: "static priority, second workgroup"}
     for form in forms:
         t = sorted(ms[form])[len(ms[form]) // 2]
         print(f"B={B} L={L} form {form} ({names.get(form, '?')}): median {t * 1e3:.1f} us per "

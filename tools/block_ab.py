@@ -3,7 +3,7 @@
 settings are interleaved round by round in ONE process (same clock, same heat), per-kernel time is the library's live hipEvent
 timing (mmada_profile_begin / _end around one block).  Minutes instead of one bench run per setting.
 
-    python tools/block_ab.py "attention_split=1" "attention_split=0" "attention_split=1,attention_skip_idle=0"
+    python tools/block_ab.py "attention_form=1" "attention_form=2"
     python tools/block_ab.py --layers 2 --batches 1,2 --rounds 6 "gemm_tile_order=0" "gemm_tile_order=1"
 """
 import argparse
@@ -70,8 +70,7 @@ def main():
                 for k in range(5):
                     acc[vi][k].append(tot[k] / max(1, n[k]))
                 for nme in names:   # back to defaults between variants
-                    lib.mmada_set_option(nme, -1 if nme in (b"gemm_config", b"attention_form", b"attention_split", b"attention_skip_idle",
-                                                             b"gemm_tile_order") else 1)
+                    lib.mmada_set_option(nme, -1 if nme in (b"gemm_config", b"attention_form", b"gemm_tile_order") else 1)
         for vi, sset in enumerate(args.settings):
             med = [sorted(a)[len(a) // 2] * 1e3 for a in acc[vi]]
             w = sorted(wall[vi])[len(wall[vi]) // 2]

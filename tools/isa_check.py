@@ -200,6 +200,13 @@ def check_gemm8(asm=None):
         lds = int(meta.get(name, {}).get("group_segment_fixed_size", "0"))
         if lds != 0:
             errors.append(f"{name}: static LDS of {lds} bytes (the kernel assumes its dynamic LDS segment starts at 0)")
+        # no scratch at all (round 5): every shipped instantiation keeps its accumulators in registers from the first MFMA to the
+        # last store.  (Round 4 shipped 20 / 52 bytes of scratch in the 320x256 SwiGLU / QKV builds: an accumulator spilled in
+        # the tail K-tiles, where hipcc picked the three-address MFMA form; csrc/gemm8.hip run() keeps them in a one-trip loop.)
+        priv = int(meta.get(name, {}).get("private_segment_fixed_size", "0"))
+        n_scratch = sum(1 for b in blocks for x in b if x.startswith("scratch_"))
+        if priv != 0 or n_scratch:
+            errors.append(f"{name}: private segment of {priv} bytes, {n_scratch} scratch instructions (a register spill)")
         if n_dma == 0 or n_saddr != n_dma:
             errors.append(f"{name}: {n_saddr} of {n_dma} LDS-DMA loads use the scalar-base form")
         # epilogues of the STORE / RESID / SwiGLU builds (template argument EPI = 0, 1, 2: every wave has the transposed

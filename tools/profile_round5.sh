@@ -1,0 +1,65 @@
+# Round-5 GPU runs (outputs under gpurun_out/r05/, summaries copied into profiles/ by hand afterwards).
+#   bash tools/profile_round5.sh [part ...]    parts: quick ab fetch peaked suite bench prof pmc tp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/r05
+mkdir -p $O
+cd $R
+export GPU_MAX_HW_QUEUES=24
+PARTS=${@:-suite bench prof pmc}
+has() { case " $PARTS " in *" $1 "*) return 0;; esac; return 1; }
+if has quick; then
+  (timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_tp.py -q -x -k "attention or sdpa or gemm_configurations or single_rank" ) > $O/quick1.log 2>&1; echo "quick1 rc=$?"; tail -n 4 $O/quick1.log
+  (timeout 900 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_cache.py -q -x -k "batch_invariance or window or cache" ) > $O/quick2.log 2>&1; echo "quick2 rc=$?"; tail -n 4 $O/quick2.log
+fi
+if has tp; then
+  (timeout 900 python -m pytest tests/test_gpu_tp.py -q -x) > $O/tp_tests.log 2>&1; echo "tp tests rc=$?"; tail -n 4 $O/tp_tests.log
+  timeout 600 python tools/tp_overlap_probe.py --cus 16,32 > $O/tp_overlap_probe.txt 2> $O/tp_overlap_probe.err; echo "overlap probe rc=$?"; cat $O/tp_overlap_probe.txt | cut -c1-900; tail -3 $O/tp_overlap_probe.err
+fi
+if has cumask; then
+  timeout 300 python tools/cu_mask_probe.py > $O/cu_mask_probe.txt 2> $O/cu_mask_probe.err; echo "cumask rc=$?"; tail -n 5 $O/cu_mask_probe.txt; tail -2 $O/cu_mask_probe.err
+fi
+if has ab2; then
+  timeout 600 python tools/block_ab.py --layers 2 --rounds 5 "gemm_tile_order=0" "gemm_tile_order=9904" > $O/block_ab2.txt 2> $O/block_ab2.err; echo "ab2 rc=$?"; cat $O/block_ab2.txt; tail -3 $O/block_ab2.err
+fi
+if has ab; then
+  timeout 600 python tools/block_ab.py --layers 2 --rounds 5 "gemm_tile_order=9904" "gemm_tile_order=408" "gemm_tile_order=216" "gemm_tile_order=804" > $O/block_ab.txt 2> $O/block_ab.err; echo "ab rc=$?"; cat $O/block_ab.txt
+fi
+if has fetch; then
+  cd /tmp && export TMPDIR=/tmp
+  timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_order -o t -- python $R/tools/tile_order_fetch.py > /dev/null 2> $O/pmc_order.err; echo "fetch rc=$?"
+  cd $R
+  python tools/tile_order_fetch.py --summarise $(ls $O/pmc_order/*/*counter_collection.csv $O/pmc_order/*counter_collection.csv 2>/dev/null | head -1) > $O/tile_order_fetch.txt 2>&1; cat $O/tile_order_fetch.txt
+  rm -rf $O/pmc_order
+fi
+if has peaked; then
+  (timeout 1200 python -m pytest tests/test_gpu_peaked.py -q -x -s -k "not flat_weights") > $O/peaked.log 2>&1; echo "peaked rc=$?"; grep -E "passed|failed|error|peaked checkpoint|M layout|M variant" $O/peaked.log | cut -c1-600
+fi
+if has suite; then (timeout 1800 python -m pytest tests -q -m gpu) > $O/pytest_gpu.log 2>&1; echo "suite rc=$?"; tail -n 3 $O/pytest_gpu.log; fi
+if has bench; then
+  timeout 600 python bench.py --steps 4 --warmup 1 > $O/bench_config1.json 2> $O/bench_config1.err; echo "bench1 rc=$?"; tail -c 1500 $O/bench_config1.json
+fi
+if has bench_others; then
+  timeout 300 python bench.py --config 0 --steps 4 --warmup 1 --no-cpu-baseline > $O/bench_config0.json 2> $O/bench_config0.err; echo "bench0 rc=$?"
+  timeout 600 python bench.py --config 3 --steps 1 --warmup 1 --no-probe --no-cpu-baseline > $O/bench_config3.json 2> $O/bench_config3.err; echo "bench3 rc=$?"
+  timeout 900 python bench.py --config 4 --graph on --steps 1 --warmup 0 --no-probe --no-cpu-baseline > $O/bench_config4.json 2> $O/bench_config4.err; echo "bench4 rc=$?"
+fi
+if has prof; then
+  cd /tmp && export TMPDIR=/tmp
+  rocprofv3 --kernel-trace --stats -d $O/kt -o r -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-probe > $O/bench_under_rocprof.json 2> $O/kt.err; echo "kt rc=$?"
+  cd $R
+  python tools/rocprof_summary.py $(ls $O/kt/*results.db 2>/dev/null | head -1) > $O/kernel_stats.csv 2>&1
+  rm -rf $O/kt
+  head -12 $O/kernel_stats.csv
+fi
+if has pmc; then
+  cd /tmp && export TMPDIR=/tmp
+  SHORT="--no-cpu-baseline --no-probe --text-steps 8 --timesteps 4 --warmup 0"
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_f -o f -- python $R/bench.py $SHORT > /dev/null 2> $O/pmc_f.err; echo "pmc_f rc=$?"
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_w -o w -- python $R/bench.py $SHORT > /dev/null 2> $O/pmc_w.err; echo "pmc_w rc=$?"
+  rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $O/pmc_t -o t -- python $R/bench.py $SHORT > /dev/null 2> $O/pmc_t.err; echo "pmc_t rc=$?"
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS --kernel-trace --output-format csv -d $O/pmc_q -o q -- python $R/bench.py $SHORT > /dev/null 2> $O/pmc_q.err; echo "pmc_q rc=$?"
+  cd $R
+  for x in f w t q; do f=$(ls $O/pmc_$x/*counter_collection.csv $O/pmc_$x/*/*counter_collection.csv 2>/dev/null | head -1); python tools/pmc_summary.py "$f" "gemm|attn|rmsnorm" > $O/pmc_$x.txt 2>&1; done
+  python tools/traffic_from_pmc.py $O/pmc_f.txt $O/pmc_w.txt $O/pmc_t.txt > $O/traffic.json 2> $O/traffic.err; tail -3 $O/traffic.err
+  rm -rf $O/pmc_f $O/pmc_w $O/pmc_t $O/pmc_q
+fi
