@@ -317,6 +317,7 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
             state["pixels"] = vq_model.decode(out_codes, force_not_quantize=True).sample.clip(0, 1)
             ev[3].record()
             state.setdefault("vq_events", []).append(ev)
+            del state["vq_events"][:-64]   # bounded: only the last steps are ever read
             state["final"] = final
             return final
 
@@ -433,14 +434,13 @@ def self_launch(n, script=None, argv=None):
     this node (one rank per GPU over RCCL; rendezvous on 127.0.0.1, a free port).  The ranks' stdout is relayed to stderr
     except rank 0's JSON line, which is printed as the LAST line of stdout; the exit code is the launcher's (non-zero if no
     line came back)."""
-    import socket
     import subprocess
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), script or os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else list(argv))
+    # the c10d rendezvous binds its own free port (endpoint port 0): no window between picking a port here and the launcher
+    # re-binding it, so concurrent benches on one node cannot collide
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--rdzv-backend=c10d",
+           "--rdzv-endpoint=127.0.0.1:0", "--local-addr", "127.0.0.1",
+           script or os.path.abspath(__file__)] + (sys.argv[1:] if argv is None else list(argv))
     env = dict(os.environ, MMADA_BENCH_SELF_LAUNCHED="1")
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
     line_out = None
@@ -619,6 +619,8 @@ def main():
                        "hipgraph_step": bool(getattr(model, "graph_replays", 0)),
                        "hipgraph_nodes_per_step_kind": {str(k): v for k, v in getattr(model, "graph_nodes", {}).items()} or None,
                        "tp_ranks_agree": ranks_agree, "tp_collective": getattr(model, "tp_collective", None),
+                       # MMADA_TP_TRANSPORT=auto|pull|copy|rccl picks the exchange's data path, MMADA_TP_EXCHANGE_CUS=n its CU partition
+                       "tp_exchange_cus": int(lib.mmada_comm_partition(h)) if getattr(model, "_comm_in_library", False) else 0,
                        # ranks of the RCCL communicators that actually exist in this run: torch.distributed's (control
                        # plane, codes all-gather) and the library's own (ncclCommCount; created beside the pull transport
                        # for the probe, or as the data path when the pull transport is not in use)

@@ -15,6 +15,8 @@ def build_product_tune(force=False):
     from mmada_parallel_amd import build as pb
 
     deps = [os.path.join(pb.CSRC, s) for s in pb.SOURCES + pb.HEADERS]
+    if os.environ.get("MMADA_TUNE_PREBUILT") == "1" and os.path.exists(PRODUCT_TUNE_LIB):
+        return PRODUCT_TUNE_LIB   # a snapshot on the GPU box: file times are those of the copy, the library travelled with it
     if not force and os.path.exists(PRODUCT_TUNE_LIB) and all(os.path.getmtime(d) < os.path.getmtime(PRODUCT_TUNE_LIB) for d in deps):
         return PRODUCT_TUNE_LIB
     objs = pb.compile_objects(os.path.join(ROOT, "tools", "_obj_tune"), extra_flags=["-DMMADA_TUNE"], force=force)

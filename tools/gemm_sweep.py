@@ -4,7 +4,7 @@ tools/libmmada_mi355x_tune.so — the same sources as the product, plus diagnost
 the 8B block.  Variant codes: 100 = the planner's pick; 300 + c = the 8-phase kernel's configuration c (0..3 ship; 4.. are
 tuning-build extras, 9..15 DIAGNOSTIC builds with wrong results: csrc/gemm8.hip launch_epi8); 1000 + BM = the 16-wave kernel.
 
-    python tools/gemm_sweep.py [--variants 100,300,301,302,303] [--m 2440,4880] [--order 0,1,2]
+    python tools/gemm_sweep.py [--variants 100,300,301,302,303] [--m 2440,4880]
 Random bf16 operands (zero-filled operands clock ~20 % higher: never bench on zeros).  Interleaved rounds, median.
 """
 import argparse
@@ -23,7 +23,6 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--variants", default="100,300,301,302,303")
     ap.add_argument("--m", default="2440,4880")
-    ap.add_argument("--order", default=None, help="comma list of gemm_tile_order values to time per variant (default: the product's)")
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--shapes", default=None, help="name:N:K,... instead of the four TP=1 projection shapes")
     ap.add_argument("--check", action="store_true")

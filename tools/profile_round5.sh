@@ -43,6 +43,15 @@ if has bench_others; then
   timeout 600 python bench.py --config 3 --steps 1 --warmup 1 --no-probe --no-cpu-baseline > $O/bench_config3.json 2> $O/bench_config3.err; echo "bench3 rc=$?"
   timeout 900 python bench.py --config 4 --graph on --steps 1 --warmup 0 --no-probe --no-cpu-baseline > $O/bench_config4.json 2> $O/bench_config4.err; echo "bench4 rc=$?"
 fi
+if has sweep; then
+  # the 32-point table the planner's constants are held against (tests/test_host_logic.py), taken with the FINAL library's
+  # -DMMADA_TUNE build (tools/build_tune.py: the product sources, no fork)
+  V=100,300,301,302,303,1320,1256
+  { echo "# tools/gemm_sweep.py on the round-5 library (-DMMADA_TUNE build of mmada_parallel_amd/csrc: tail K-tiles in a one-trip loop, 4x8 tile order for 320x256), cold operands (6 rotating copies), random bf16, STORE epilogue.  v100 = the planner's pick; v300-303 = 8-phase 320x256 / 256x256 / 160x256 / 320x128; v1320 / v1256 = the 16-wave kernel with BM 320 / 256.  TFLOP/s, median of 3 rounds.";
+    MMADA_TUNE_PREBUILT=1 timeout 400 python tools/gemm_sweep.py --variants $V --rounds 3 --m 2440,4880;
+    MMADA_TUNE_PREBUILT=1 timeout 400 python tools/gemm_sweep.py --variants $V --rounds 3 --m 4880,9760 --shapes qkv2:6144:4096,o2:4096:2048,gu2:12288:4096,dn2:4096:6144,qkv4:3072:4096,o4:4096:1024,gu4:6144:4096,dn4:4096:3072;
+    MMADA_TUNE_PREBUILT=1 timeout 400 python tools/gemm_sweep.py --variants $V --rounds 3 --m 19520 --shapes qkv8:1536:4096,o8:4096:512,gu8:3072:4096,dn8:4096:1536,qkv4:3072:4096,o4:4096:1024,gu4:6144:4096,dn4:4096:3072; } > $O/gemm8_sweep_final.txt 2> $O/gemm8_sweep.err; echo "sweep rc=$?"; tail -n 12 $O/gemm8_sweep_final.txt
+fi
 if has prof; then
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --stats -d $O/kt -o r -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-probe > $O/bench_under_rocprof.json 2> $O/kt.err; echo "kt rc=$?"
