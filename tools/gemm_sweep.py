@@ -35,7 +35,8 @@ def main():
         shapes = {n: (int(a), int(b)) for n, a, b in (x.split(":") for x in args.shapes.split(","))}
     import ctypes
 
-    lib = ctypes.CDLL(build_product_tune())
+    raw = ctypes.CDLL(build_product_tune())
+    lib = raw
     lib.mmada_gemm_bt.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p]
     lib.mmada_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
     lib.mmada_last_error.restype = ctypes.c_char_p
@@ -43,12 +44,12 @@ def main():
     class _V:
         @staticmethod
         def mmada_gemm_variant(v, A, W, C, M, N, K, st):
-            lib.mmada_set_option(b"gemm_config", -1 if v == 100 else (v - 300 if 300 <= v < 1000 else v))
-            rc = lib.mmada_gemm_bt(A, W, C, M, N, K, st)
-            lib.mmada_set_option(b"gemm_config", -1)
+            raw.mmada_set_option(b"gemm_config", -1 if v == 100 else (v - 300 if 300 <= v < 1000 else v))
+            rc = raw.mmada_gemm_bt(A, W, C, M, N, K, st)
+            raw.mmada_set_option(b"gemm_config", -1)
             return rc
 
-    lib_raw, lib = lib, _V
+    lib = _V
     dev = "cuda:0"
     variants = [int(v) for v in args.variants.split(",")]
     st = torch.cuda.current_stream().cuda_stream
