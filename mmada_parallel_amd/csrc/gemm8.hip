@@ -10,10 +10,10 @@
 //     in registers for two phases) against one W half (FB fragments x 2 k-steps):
 //         P1 (A0,B0)   P2 (A0,B1)   P3 (A1,B1)   P4 (A1,B0)
 //     phase = { LDS-DMA issue for a later K-tile ; ds_read_b128 of ONE operand half ; counted vmcnt ; barrier ;
-//               MFMA cluster ; barrier }.  Balanced schedule (tile_bal: the 256x256 / 160x256 / 320x128 tiles): P1 reads A0,
+//               MFMA cluster ; barrier }.  Balanced schedule (tile_bal: every shipped tile since round 5): P1 reads A0,
 //     P2 B1, P3 A1 and P4 the NEXT K-tile's B0 (into the W registers P3 released), so no phase has to fetch two halves
-//     while its SIMD partner is only 20 MFMAs long.  First schedule (tile: the 320x256 tile, whose RESID / QKV builds would
-//     spill inside the loop with the other one): P1 reads A0 and B0, P2 B1, P3 A1, P4 nothing.  launch_epi8 picks.
+//     while its SIMD partner is only 20 MFMAs long.  First schedule (tile: tuning builds only since round 5; the 320x256 tile
+//     shipped it while its balanced RESID / QKV builds still spilled): P1 reads A0 and B0, P2 B1, P3 A1, P4 nothing.
 //   * the LDS image of a K-tile is cut the same way into four HALF-TILES (A0, A1, B0, B1 = the rows every wave reads for
 //     that half).  A half-tile slot is re-filled two phases after its last ds_read, with the data of the K-tile AFTER next:
 //     four half-tiles (one whole K-tile, up to 72 KiB per CU) are always in flight, each issued at least four phases — one
@@ -461,16 +461,18 @@ template <int EPI>
 int launch_epi8(int cfg, const GemmArgs& g, hipStream_t s) {
     constexpr int SW = EPI == EPI_QKV ? 2 : 1;
     switch (cfg) {
-        // the balanced read schedule (OPT 2) wherever it fits the registers: +1-3 % (profiles/r03_gemm8_sweep5_balanced.txt);
-        // the 320 x 256 tile spills inside the loop with it in the RESID / QKV epilogue builds and gains nothing on gate/up
-        case GEMM8_320x256: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 0>>(g, s);
+        // the balanced read schedule (OPT 2) on every tile.  Rounds 3-4 kept the first schedule on 320 x 256 because its RESID /
+        // QKV builds spilled inside the loop with the balanced one; with the tail K-tiles in a one-trip loop (run()) all four
+        // epilogues compile spill-free (254-255 VGPRs) and the in-model A/B reads +0.4 ... 1.0 % on gate/up and QKV, +-0 on the
+        // rest (profiles/r05_block_ab_balanced.txt; tuning build: configuration 6 = the first schedule)
+        case GEMM8_320x256: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 2>>(g, s);
         case GEMM8_256x256: return launch_cfg8<EPI, Gemm8<256, 256, 2, 4, SW, 2>>(g, s);
         case GEMM8_160x256: return launch_cfg8<EPI, Gemm8<160, 256, 2, 4, SW, 2>>(g, s);
         case GEMM8_320x128: return launch_cfg8<EPI, Gemm8<320, 128, 4, 2, SW, 2>>(g, s);
 #ifdef MMADA_TUNE
-        case 4: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 1>>(g, s);
+        case 4: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 3>>(g, s);    // balanced + static s_setprio for the late group
         case 5: return launch_cfg8<EPI, Gemm8<320, 128, 4, 2, SW, 0>>(g, s);
-        case 6: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 2>>(g, s);
+        case 6: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 0>>(g, s);    // the first read schedule (rounds 3-4 production)
         case 7: return launch_cfg8<EPI, Gemm8<256, 256, 2, 4, SW, 0>>(g, s);
         case 8: return launch_cfg8<EPI, Gemm8<160, 256, 2, 4, SW, 0>>(g, s);
         case 9: return launch_cfg8<EPI, Gemm8<320, 256, 2, 4, SW, 4>>(g, s);    // DIAG: no MFMA

@@ -488,7 +488,7 @@ class LLaDAForMultiModalGeneration:
             lib.mmada_comm_destroy(self._handle)
             chosen = "host all-reduce (torch.distributed)"
         self._rccl_also = False
-        if chosen == "pull" and os.environ.get("MMADA_TP_PROBE_RCCL", "0") == "1":
+        if chosen in ("pull", "copy") and os.environ.get("MMADA_TP_PROBE_RCCL", "0") == "1":
             # OPT-IN (bench.py sets it): one rank per device over RCCL as well, so that collective_probe() can time BOTH
             # transports.  A production start does not pay a second communicator (init time, memory, one more thing that
             # can fail or hang at start-up).
@@ -502,7 +502,7 @@ class LLaDAForMultiModalGeneration:
                     try:
                         ok = lib.mmada_comm_connect_rccl(self._handle, box[0], path) == 0   # leaves mode = RCCL
                     finally:
-                        lib.mmada_comm_set_mode(self._handle, 1)                         # the forward keeps the pull transport
+                        lib.mmada_comm_set_mode(self._handle, 4 if chosen == "copy" else 1)   # the forward keeps its transport
                     self._rccl_also = all_agree(ok)
         self.tp_collective = chosen
         cus = int(os.environ.get("MMADA_TP_EXCHANGE_CUS", "0") or 0)
@@ -539,7 +539,22 @@ class LLaDAForMultiModalGeneration:
         out = {"transport": self.tp_collective, "rows": B * L, "bytes": nbytes, "ms": ms,
                "busbw_GBps": 2.0 * (tp - 1) / tp * nbytes / (ms * 1e-3) / 1e9, "exchanges_per_forward": 2 * self.config.n_layers,
                "status": self.comm_status()}
-        if getattr(self, "_rccl_also", False) and self.tp_collective == "pull":   # the same exchange over RCCL, for comparison
+        if self.tp_collective in ("pull", "copy"):   # the other data path over the same mapped buffers, for comparison
+            other, mode_other, mode_back = ("copy", 4, 1) if self.tp_collective == "pull" else ("pull", 1, 4)
+            abi.check(self._lib.mmada_comm_set_mode(self._handle, mode_other), "mmada_comm_set_mode")
+            try:
+                for _ in range(3):
+                    abi.check(self._lib.mmada_comm_exchange(self._handle, w.data_ptr(), st), "mmada_comm_exchange")
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    abi.check(self._lib.mmada_comm_exchange(self._handle, w.data_ptr(), st), "mmada_comm_exchange")
+                torch.cuda.synchronize()
+                ms3 = (time.perf_counter() - t0) / iters * 1e3
+                out[other] = {"ms": ms3, "busbw_GBps": 2.0 * (tp - 1) / tp * nbytes / (ms3 * 1e-3) / 1e9}
+            finally:
+                abi.check(self._lib.mmada_comm_set_mode(self._handle, mode_back), "mmada_comm_set_mode")
+        if getattr(self, "_rccl_also", False) and self.tp_collective in ("pull", "copy"):   # the same exchange over RCCL, for comparison
             abi.check(self._lib.mmada_comm_set_mode(self._handle, 2), "mmada_comm_set_mode")
             try:
                 for _ in range(3):
@@ -552,7 +567,7 @@ class LLaDAForMultiModalGeneration:
                 ms2 = (time.perf_counter() - t0) / iters * 1e3
                 out["rccl"] = {"ms": ms2, "busbw_GBps": 2.0 * (tp - 1) / tp * nbytes / (ms2 * 1e-3) / 1e9}
             finally:
-                abi.check(self._lib.mmada_comm_set_mode(self._handle, 1), "mmada_comm_set_mode")
+                abi.check(self._lib.mmada_comm_set_mode(self._handle, 4 if self.tp_collective == "copy" else 1), "mmada_comm_set_mode")
         return out
 
     def rccl_nranks(self) -> int:

@@ -52,6 +52,23 @@ if has sweep; then
     MMADA_TUNE_PREBUILT=1 timeout 400 python tools/gemm_sweep.py --variants $V --rounds 3 --m 4880,9760 --shapes qkv2:6144:4096,o2:4096:2048,gu2:12288:4096,dn2:4096:6144,qkv4:3072:4096,o4:4096:1024,gu4:6144:4096,dn4:4096:3072;
     MMADA_TUNE_PREBUILT=1 timeout 400 python tools/gemm_sweep.py --variants $V --rounds 3 --m 19520 --shapes qkv8:1536:4096,o8:4096:512,gu8:3072:4096,dn8:4096:1536,qkv4:3072:4096,o4:4096:1024,gu4:6144:4096,dn4:4096:3072; } > $O/gemm8_sweep_final.txt 2> $O/gemm8_sweep.err; echo "sweep rc=$?"; tail -n 12 $O/gemm8_sweep_final.txt
 fi
+if has bal; then
+  # the balanced read schedule on the 320x256 tile (tuning build: configuration 6) against the shipped first schedule (0), every
+  # GEMM of the block pinned to the tile: spill-free for every epilogue since the tail K-tiles sit in a one-trip loop
+  MMADA_MI355X_LIB=$R/tools/libmmada_mi355x_tune.so timeout 600 python tools/block_ab.py --layers 2 --rounds 7 "gemm_config=0" "gemm_config=6" "gemm_config=4" > $O/block_ab_balanced.txt 2> $O/block_ab_balanced.err; echo "bal rc=$?"; cat $O/block_ab_balanced.txt; tail -2 $O/block_ab_balanced.err
+fi
+if has cfgab; then
+  # every GEMM of the block pinned to one tile configuration in turn (product library): which tile each projection wants at B = 1 / 2
+  timeout 600 python tools/block_ab.py --layers 2 --rounds 5 "gemm_config=-1" "gemm_config=0" "gemm_config=1" "gemm_config=2" "gemm_config=3" > $O/block_ab_configs.txt 2> $O/block_ab_configs.err; echo "cfgab rc=$?"; cat $O/block_ab_configs.txt; tail -2 $O/block_ab_configs.err
+fi
+if has diag; then
+  # where the main loop's time goes, with the round-5 kernels: the DIAGNOSTIC builds of the 320x256 tile in the -DMMADA_TUNE library
+  # (wrong results, timing only; numbers = the TFLOP/s the real GEMM would have at that duration).  300 production; 309 no MFMA;
+  # 310 no LDS-DMA; 311 no ds_read; 312 MFMAs + barriers only; 313 LDS-DMA + barriers only; 314 the same, every request an L2 hit;
+  # 315 whole kernel, every request an L2 hit; 304 static s_setprio for the late wave group; 306 the balanced read schedule
+  { echo "# tools/gemm_sweep.py --variants 300,309,...: diagnostic builds of gemm8 320x256 (csrc/gemm8.hip launch_epi8, -DMMADA_TUNE), gate/up and down shapes, STORE epilogue, cold operands, random bf16";
+    MMADA_TUNE_PREBUILT=1 timeout 400 python tools/gemm_sweep.py --variants 300,304,306,309,310,311,312,313,314,315 --rounds 25 --m 2440,4880 --shapes gateup:24576:4096,down:4096:12288; } > $O/gemm8_diagnostics.txt 2> $O/gemm8_diagnostics.err; echo "diag rc=$?"; cat $O/gemm8_diagnostics.txt; tail -2 $O/gemm8_diagnostics.err
+fi
 if has prof; then
   cd /tmp && export TMPDIR=/tmp
   rocprofv3 --kernel-trace --stats -d $O/kt -o r -- python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-probe > $O/bench_under_rocprof.json 2> $O/kt.err; echo "kt rc=$?"
