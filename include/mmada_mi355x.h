@@ -131,7 +131,9 @@ int mmada_set_consumed_rows(mmada_handle* h, int row_begin, int row_end);
 size_t mmada_cache_bytes(const mmada_handle* h, int B, int L);
 /* Attach `mem` (256-byte aligned, >= mmada_cache_bytes) as slot `slot` in [0,16) and zero it on `stream` — the reference
  * creates a cache with torch.zeros_like (:930-932,1407-1408), so never-computed positions have zero keys, values and
- * logits.  mem == NULL forgets the slot (empty_cache()).  tp_size must be 1. */
+ * logits.  mem == NULL forgets the slot (empty_cache()).  Tensor parallel (round 5): with the library's exchange connected a slot
+ * holds THIS rank's heads of every block's keys / values, and the final rows it keeps are already ln_f-normalised (the last
+ * exchange of a tensor-parallel forward applies ln_f on the owners' rows and all-gathers them). */
 int mmada_cache_bind(mmada_handle* h, int slot, void* mem, size_t bytes, int B, int L, void* stream);
 /* One forward through slot `slot`.  pos == NULL: every token is computed (ids [B,L]); keys / values / final stream of the
  * whole sequence are stored (the reference's use_cache=True, to_compute_mask=None call).  pos != NULL: ids [B,Tc] are

@@ -380,7 +380,8 @@ int mmada_cache_bind(mmada_handle* h, int slot, void* mem, size_t bytes, int B, 
         h->slots[slot] = CacheSlot{};
         return 0;
     }
-    if (h->cfg.tp_size != 1) return mm_fail("mmada_cache_bind: the dLLM cache path is single-rank (tp_size=%d)", h->cfg.tp_size);
+    if (h->cfg.tp_size != 1 && !tp_comm_connected(h))
+        return mm_fail("mmada_cache_bind: tp_size=%d needs the library's exchange connected (mmada_comm_create + mmada_comm_connect_*)", h->cfg.tp_size);
     if (B <= 0 || L <= 0 || L > h->cfg.max_seq) return mm_fail("mmada_cache_bind: bad shape B=%d L=%d", B, L);
     if (((uintptr_t)mem) & 255) return mm_fail("mmada_cache_bind: memory must be 256-byte aligned");
     CacheSlot c;
@@ -400,7 +401,8 @@ int mmada_forward_cached(mmada_handle* h, int slot, const int64_t* ids, const in
     if (slot < 0 || slot >= MMADA_CACHE_SLOTS || !h->slots[slot].mem) return mm_fail("mmada_forward_cached: slot %d is not bound", slot);
     const CacheSlot& c = h->slots[slot];
     if (c.B != B || c.L != L) return mm_fail("mmada_forward_cached: slot holds B=%d L=%d, call has B=%d L=%d", c.B, c.L, B, L);
-    if (h->cfg.tp_size != 1) return mm_fail("mmada_forward_cached: single-rank only");
+    const bool tp = h->cfg.tp_size != 1 || tp_comm_connected(h);
+    if (tp && !tp_comm_connected(h)) return mm_fail("mmada_forward_cached: tp_size=%d needs the library's exchange connected", h->cfg.tp_size);
     if (!pos) Tc = L;
     if (Tc <= 0 || Tc > L) return mm_fail("mmada_forward_cached: Tc=%d outside (0,%d]", Tc, L);
     hipStream_t s = (hipStream_t)stream;
@@ -424,20 +426,29 @@ int mmada_forward_cached(mmada_handle* h, int slot, const int64_t* ids, const in
     h->cc_pos = pos ? h->posmap : nullptr;
     h->cc_qshift = (pos && !q_pos_from_map) ? L - Tc : -1;
     int rc = 0;
-    for (int i = 0; i < h->cfg.n_layers && !rc; ++i) {
-        rc = mmada_attn_partial(h, i, stream);
-        if (!rc) rc = mmada_mlp_partial(h, i, stream);
+    if (tp) {
+        // tensor parallel: the blocks, their exchanges and the cache hooks of this rank's heads run in tp_forward_body; its last
+        // exchange leaves xn = ln_f(x) on EVERY row of every rank, which is what the slot keeps (CacheSlot::normalized)
+        rc = tp_forward_body(h, s);
+    } else {
+        for (int i = 0; i < h->cfg.n_layers && !rc; ++i) {
+            rc = mmada_attn_partial(h, i, stream);
+            if (!rc) rc = mmada_mlp_partial(h, i, stream);
+        }
     }
     h->cc = nullptr; h->cc_pos = nullptr; h->cc_qshift = -1;
     if (rc) { h->M = 0; return 1; }
     // the rows just computed replace theirs in the slot's final residual stream (the reference scatters the logits,
     // :1409-1411; a logit row is a function of its residual row alone, so the head runs on demand: mmada_cache_head_rows)
     bf16_t* xfin = c.xfin(h->cfg.n_layers);
+    const bf16_t* fin = tp ? h->xn : h->x;
+    h->slots[slot].normalized = tp;
     if (pos) {
-        if (launch_scatter_rows(h->x, xfin, h->posmap, h->M, h->Lp, c.Lp, d, s)) { h->M = 0; return 1; }
+        if (launch_scatter_rows(fin, xfin, h->posmap, h->M, h->Lp, c.Lp, d, s)) { h->M = 0; return 1; }
     } else {
-        MM_CHECK_HIP(hipMemcpyAsync(xfin, h->x, (size_t)h->M * d * 2, hipMemcpyDeviceToDevice, s));
+        MM_CHECK_HIP(hipMemcpyAsync(xfin, fin, (size_t)h->M * d * 2, hipMemcpyDeviceToDevice, s));
     }
+    h->xn_is_final = false;
     h->M = 0;  // no plain forward is resident: mmada_head_rows / mmada_read_stream must not read the compact stream
     return 0;
 }
@@ -466,7 +477,9 @@ int mmada_cache_head_rows(mmada_handle* h, int slot, const int32_t* rows, int R,
         if (!h->ws || cv.total > h->ws_bytes) return mm_fail("mmada_cache_head_rows: workspace too small (%zu needed)", cv.total);
         xg = (bf16_t*)(h->ws + cv.xg);
     }
-    if (launch_rmsnorm_gather(c.xfin(h->cfg.n_layers), h->ln_f, xg, rows, R, c.L, c.Lp, d, h->cfg.rms_eps, s, 0, c.B * c.L))
+    if (c.normalized) {   // rows written by a tensor-parallel forward: ln_f already applied by the owners
+        if (tp_gather_rows(c.xfin(h->cfg.n_layers), rows, R, c.L, c.Lp, d, c.B * c.L, xg, s)) return 1;
+    } else if (launch_rmsnorm_gather(c.xfin(h->cfg.n_layers), h->ln_f, xg, rows, R, c.L, c.Lp, d, h->cfg.rms_eps, s, 0, c.B * c.L))
         return 1;
     GemmArgs g{};
     g.A = xg; g.W = h->lm_head + (size_t)col_begin * d; g.C = (bf16_t*)logits_out;

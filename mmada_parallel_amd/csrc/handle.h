@@ -25,6 +25,8 @@ struct CacheSlot {
     char* mem = nullptr;
     size_t bytes = 0, layer_stride = 0, kv_bytes = 0;
     int B = 0, L = 0, Lp = 0, Lkv = 0;
+    bool normalized = false;   // the final rows are ALREADY ln_f-normalised (written by a tensor-parallel forward, whose last
+                               // exchange applies ln_f on the owners' rows): mmada_cache_head_rows gathers them without a norm
     bf16_t* K(int layer) const { return (bf16_t*)(mem + (size_t)layer * layer_stride); }
     bf16_t* vT(int layer) const { return (bf16_t*)(mem + (size_t)layer * layer_stride + kv_bytes); }
     bf16_t* xfin(int n_layers) const { return (bf16_t*)(mem + (size_t)n_layers * layer_stride); }
@@ -79,6 +81,8 @@ void tp_comm_free(mmada_handle* h);
 void tp_allow_single_rank(int on);   // test switch: mmada_comm_create accepts tp_size == 1
 bool tp_comm_connected(const mmada_handle* h);   // a transport (or the no-exchange diagnostic) is active on this handle
 int tp_head_gather(mmada_handle* h, const int32_t* rows, int R, hipStream_t s);  // xg[r] = xn[row r] (xn already = ln_f(x))
+// out[r] = src[b * Lp + l] for rows[r] = b * L + l: the plain row gather behind tp_head_gather, on any [B * Lp, d] buffer
+int tp_gather_rows(const bf16_t* src, const int32_t* rows, int R, int L, int Lp, int d, int nflat, bf16_t* out, hipStream_t s);
 
 struct ProfScope {
     mmada_handle* h; hipStream_t s; bool on; hipEvent_t a{}, b{}; int kind; double flops;

@@ -502,6 +502,7 @@ static int tp_forward_body_on(mmada_handle* h, hipStream_t s) {
     Slice sl[2];
     for (int k = 0; k < nch; ++k) sl[k] = chunk_slice(M, tp, c->rank, nch, k);
     const double rows_real = (double)h->B * h->L / M;  // fraction of stream rows that are not padding (FLOP accounting)
+    const CacheSlot* cc = h->cc;
     // first RMSNorm of the forward: the embeddings are replicated, no exchange needed
     if (h->xn_is_layer0) h->xn_is_layer0 = false;  // fused into the embedding kernel
     else if (launch_rmsnorm(h->x, h->layers[0].attn_norm, h->xn, M, d, h->cfg.rms_eps, s)) return 1;
@@ -532,13 +533,20 @@ static int tp_forward_body_on(mmada_handle* h, hipStream_t s) {
             g.lda = d; g.ldw = d; g.ldc = 0; g.m_base = sl[k].m0;
             g.q = h->q; g.k = h->k; g.vT = h->vT; g.rope_cos = h->rope_cos; g.rope_sin = h->rope_sin;
             g.Lp = h->Lp; g.Lkv = h->Lkv; g.Hq = h->hq_l; g.Hkv = h->hkv_l;
+            if (cc) {   // dLLM cache step (mmada_forward_cached): this rank's heads of the block's keys / values live in the slot
+                g.k = cc->K(layer); g.vT = cc->vT(layer); g.Lkv = cc->Lkv;
+                g.pos_map = h->cc_pos; g.Lq = h->Lkv; g.q_pos_shift = h->cc_qshift;
+            }
             ProfScope p(h, layer, 0, 2.0 * g.M * rows_real * g.N * g.K, s);
             if (launch_gemm(EPI_QKV, g, s)) return 1;
         }
         {   // ---- attention over this rank's heads: the one join point (every key of a sequence) ----
-            ProfScope p(h, layer, 1, 4.0 * h->hq_l * (double)h->B * h->L * h->L * 128.0, s);
-            if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->Lp, h->Lkv, h->Lp,
-                                 h->hq_l * 128, s)) return 1;
+            ProfScope p(h, layer, 1, 4.0 * h->hq_l * (double)h->B * h->L * (cc ? cc->L : h->L) * 128.0, s);
+            if (cc) {   // compact (or all) queries of this call against the slot's keys / values of the whole sequence
+                if (launch_attention(h->q, cc->K(layer), cc->vT(layer), h->att, h->B, h->hq_l, h->hkv_l, cc->L, h->Lp, cc->Lkv,
+                                     h->Lp, h->hq_l * 128, s, 0, h->Lkv)) return 1;
+            } else if (launch_attention(h->q, h->k, h->vT, h->att, h->B, h->hq_l, h->hkv_l, h->L, h->Lp, h->Lkv, h->Lp,
+                                        h->hq_l * 128, s)) return 1;
         }
         // ---- attn_out (row-parallel) chunk by chunk; chunk k's exchange runs under chunk k+1's GEMM ----
         for (int k = 0; k < nch; ++k) {
@@ -935,6 +943,12 @@ int mmada_comm_destroy(mmada_handle* h) {
 }
 
 }  // extern "C"
+
+int tp_gather_rows(const bf16_t* src, const int32_t* rows, int R, int L, int Lp, int d, int nflat, bf16_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, s, src, rows, R, L, Lp, d, nflat, out);
+    MM_CHECK_HIP(hipGetLastError());
+    return 0;
+}
 
 int tp_head_gather(mmada_handle* h, const int32_t* rows, int R, hipStream_t s) {
     hipLaunchKernelGGL(gather_rows_kernel, dim3((R + 3) / 4), dim3(256), 0, s, h->xn, rows, R, h->L, h->Lp, h->cfg.d_model,

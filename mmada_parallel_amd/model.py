@@ -668,10 +668,12 @@ class LLaDAForMultiModalGeneration:
         """One forward through the cache slot `cat` (created at zeros on first use, like the reference's zeros_like).
         Mask None: every token is computed and the slot is (re)filled.  Mask [B, L] bool with the same count in every
         row (the reference's `.view(B, -1)`): only those tokens run through the blocks; read logits with cache_head_rows."""
-        if self.tp_size != 1:
-            raise NotImplementedError("the dLLM cache path is single-rank (tp_size == 1)")
+        if self.tp_size != 1 and not self._comm_in_library:
+            raise NotImplementedError("the dLLM cache path under tensor parallelism needs the library's exchange (init_tp_comm)")
         ids = input_ids.to(device=self.device, dtype=torch.long).contiguous()
         B, L = ids.shape
+        if self._comm_in_library and B * ((L + 7) // 8 * 8) > self._comm_rows:
+            raise abi.MmadaError(f"cached forward of {B}x{L} exceeds the {self._comm_rows} rows init_tp_comm() was sized for")
         self._ensure_ws(B, L)
         ent = self._cache_slot(cat, B, L, rebind_ok=to_compute_mask is None)
         st = abi.stream_ptr()

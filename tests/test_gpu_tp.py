@@ -271,3 +271,55 @@ def test_single_rank_group_runs_the_whole_transport_and_equals_the_plain_forward
         lib.mmada_set_option(b"tp_allow_single_rank", 0)
         lib.mmada_comm_destroy(m._handle)
         m._comm_in_library = False
+
+
+def test_dllm_cache_under_tensor_parallelism(tiny_tp1):
+    """The dLLM cache branch (model/modeling_llada.py:593-600,929-940,1244-1245,1406-1426; mmada_cache_* / mmada_forward_cached)
+    with the library's tensor-parallel exchange connected (round 5: every rank caches ITS heads of each block's keys / values;
+    the slot's final rows are the all-gathered ln_f rows).  Exact properties on a TP = 2 group: a prime call and a mask over
+    every token equal the plain tensor-parallel forward bit for bit; rows outside a compute mask keep their logits bit for bit
+    and the computed ones change; the ranks agree bit for bit.  Against TP = 1 on the same script: within the bf16 partial-sum
+    tolerance of the tensor-parallel forward."""
+    tp = 2
+    (_, ids0, _), (_, ids1, m1) = synth.dllm_cache_script()[:2]
+    B, L = ids0.shape
+    Lp = (L + 7) // 8 * 8
+    ranks, streams = _group(synth.CFG_TINY, tiny_sd(), tp, B * Lp)
+    ids0, ids1, m1 = ids0.to(DEV), ids1.to(DEV), m1.to(DEV)   # on the device BEFORE any rank enqueues (no host copy between ranks)
+    lo, hi = synth.TEXT_VOCAB, synth.TEXT_VOCAB + 512
+    rows = torch.arange(B * L, dtype=torch.int32, device=DEV)
+    for m in ranks + [tiny_tp1]:
+        m.caching(True)
+
+    def plain(m, ids):
+        m.forward_body(ids)
+        return m.head_rows(rows, lo, hi).clone()
+
+    def cached(m, ids, mask):
+        m.forward_cached(ids, mask, cat="c")
+        return m.cache_head_rows("c", rows, lo, hi).clone()
+
+    plain0 = _each(ranks, streams, lambda m: plain(m, ids0))
+    primed = _each(ranks, streams, lambda m: cached(m, ids0, None))
+    assert torch.equal(plain0[0], plain0[1]) and torch.equal(primed[0], primed[1]), "ranks must agree bit for bit"
+    assert torch.equal(primed[0], plain0[0]), "a prime call is the plain tensor-parallel forward"
+    step = _each(ranks, streams, lambda m: cached(m, ids1, m1))
+    assert torch.equal(step[0], step[1])
+    keep = (~m1).reshape(-1).to(DEV)
+    assert torch.equal(step[0][keep], primed[0][keep]), "rows outside the compute mask keep their logits"
+    assert not torch.equal(step[0][~keep], primed[0][~keep])
+    plain1 = _each(ranks, streams, lambda m: plain(m, ids1))
+    full = _each(ranks, streams, lambda m: cached(m, ids1, torch.ones_like(m1)))
+    assert torch.equal(full[0], plain1[0]), "a mask over every token is the plain tensor-parallel forward"
+    # the same script on one rank
+    ref_primed = cached(tiny_tp1, ids0, None).float()
+    ref_step = cached(tiny_tp1, ids1, m1).float()
+    for got, ref, what in ((primed[0], ref_primed, "prime"), (step[0], ref_step, "compute-mask step")):
+        err = (got.float() - ref).abs()
+        scale = ref.abs().max().item()
+        print(f"dLLM cache, TP=2 vs TP=1, {what}: max {err.max().item() / scale:.3e} mean {err.mean().item() / scale:.3e}")
+        assert err.max().item() < 4e-2 * scale and err.mean().item() < 6e-3 * scale
+    for m in ranks:
+        assert m.comm_status()["error"] == 0
+        m.empty_cache()
+    tiny_tp1.empty_cache()
