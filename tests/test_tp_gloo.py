@@ -184,3 +184,20 @@ def test_chunk_slices_cover_rows_once_and_match_padding_rules():
                         seen[r0:r1] += 1
                 assert bool((seen == 1).all()), (size, M, nch)
     assert tp.vocab_slice(134656, 7, 8) == (117824, 134656) and tp.vocab_slice(134656, 0, 8) == (0, 16832)
+
+
+def test_exchange_plan_degenerates_cleanly_to_one_rank():
+    """The single-rank test switch of the library (mmada_set_option("tp_allow_single_rank"): tests/test_gpu_tp.py runs every
+    transport on a one-rank group) relies on the exchange plan being well formed for size 1: one owner that owns every row of
+    each chunk, chunks that tile [0, M) without overlap, and a vocabulary slice that is the whole head."""
+    from mmada_parallel_amd import tp
+
+    for M in (8, 24, 96, 2440, 4880):
+        for nch in (1, 2):
+            sl = tp.chunk_slices(M, 1, nch)
+            assert sl[0][0] == 0 and sl[-1][1] == M and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+            own = tp.owned_rows(M, 0, 1, nch)
+            assert [(m0, m1) for m0, m1, _ in sl] == own, "the one rank owns every row"
+            for m0, m1, s in sl:
+                assert s >= m1 - m0 and s % 8 == 0
+    assert tp.vocab_slice(134656, 0, 1) == (0, 134656)
