@@ -1,6 +1,6 @@
-# SQ counters of the attention forms (separate rocprofv3 --pmc pass, kernel trace only): bash tools/attn_pmc.sh "1,2"
+# SQ counters of the attention forms (separate rocprofv3 --pmc pass, kernel trace only): bash tools/attn_pmc.sh "0,1"
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-FORMS=${1:-1,2}
+FORMS=${1:-0,1}
 O=$R/gpurun_out/r04/attn_pmc
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,6 @@
-# kernel-only times of the attention forms under rocprofv3 (kernel trace): bash tools/attn_prof.sh "1,2" OUTDIR
+# kernel-only times of the attention forms under rocprofv3 (kernel trace): bash tools/attn_prof.sh "0,1" OUTDIR
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-FORMS=${1:-1,2}
+FORMS=${1:-0,1}
 O=${2:-$R/gpurun_out/r04/attn}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp

@@ -1,5 +1,5 @@
 """A/B of attention forms (and of the GEMM's short row tiles: "1:0" = form 1, short tiles off) inside the headline bench
-(short runs): python tools/bench_forms.py 1 2 1:0 1 2"""
+(short runs): python tools/bench_forms.py 1 0 1:0 1 0"""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for f in sys.argv[1:]:
