@@ -57,6 +57,14 @@ if has bal; then
   # GEMM of the block pinned to the tile: spill-free for every epilogue since the tail K-tiles sit in a one-trip loop
   MMADA_MI355X_LIB=$R/tools/libmmada_mi355x_tune.so timeout 600 python tools/block_ab.py --layers 2 --rounds 7 "gemm_config=0" "gemm_config=6" "gemm_config=4" > $O/block_ab_balanced.txt 2> $O/block_ab_balanced.err; echo "bal rc=$?"; cat $O/block_ab_balanced.txt; tail -2 $O/block_ab_balanced.err
 fi
+if has rig; then
+  # the driver's multi-GPU command on the one-GPU rig (N tensor-parallel processes sharing this GPU over hipIpc, gloo control plane):
+  # functional check of every data path the first multi-GPU session may select — not a throughput measurement
+  for t in pull copy; do
+    MMADA_TP_TRANSPORT=$t MMADA_BENCH_ONE_GPU=1 timeout 600 python bench.py --gpus 2 --steps 1 --warmup 1 --layers 4 --text-steps 16 --timesteps 8 --no-cpu-baseline --no-probe > $O/rig_tp2_$t.json 2> $O/rig_tp2_$t.err; echo "rig tp2 $t rc=$?"; tail -c 1800 $O/rig_tp2_$t.json | head -c 1800; echo
+  done
+  MMADA_TP_TRANSPORT=copy MMADA_BENCH_ONE_GPU=1 timeout 600 python bench.py --gpus 4 --steps 1 --warmup 1 --layers 4 --text-steps 16 --timesteps 8 --no-cpu-baseline --no-probe > $O/rig_tp4_copy.json 2> $O/rig_tp4_copy.err; echo "rig tp4 copy rc=$?"
+fi
 if has cfgab; then
   # every GEMM of the block pinned to one tile configuration in turn (product library): which tile each projection wants at B = 1 / 2
   timeout 600 python tools/block_ab.py --layers 2 --rounds 5 "gemm_config=-1" "gemm_config=0" "gemm_config=1" "gemm_config=2" "gemm_config=3" > $O/block_ab_configs.txt 2> $O/block_ab_configs.err; echo "cfgab rc=$?"; cat $O/block_ab_configs.txt; tail -2 $O/block_ab_configs.err
