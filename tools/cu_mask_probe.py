@@ -39,9 +39,19 @@ def main():
     for b in range(ncu):
         s = where(lib, [b], ncu, 512)
         per_bit[b] = sorted(s)
+    # An XCD whose share of the mask is all zero is NOT restricted (observed: a one-bit mask pins one XCD to one CU and leaves
+    # the other seven whole), so the CU a bit selects is the lone CU of the XCD that shows fewer CUs than the rest.
+    def pinned(seen):
+        per = {}
+        for t in seen:
+            per.setdefault(t[0], []).append(t[1:])
+        few = [(x, c) for x, c in per.items() if len(c) == 1]
+        return (few[0][0],) + few[0][1][0] if len(few) == 1 else None
+
+    sel = {b: pinned(per_bit[b]) for b in per_bit}
     for b in range(ncu):
-        print(f"bit {b:3d} -> (xcd, se, sh, cu) {per_bit[b]}")
-    xcd_of = {b: per_bit[b][0][0] if per_bit[b] else None for b in per_bit}
+        print(f"bit {b:3d} -> (xcd, se, sh, cu) {sel[b]}")
+    xcd_of = {b: sel[b][0] if sel[b] else None for b in sel}
     for n in (8, 16, 32):
         low = [xcd_of[b] for b in range(n)]
         print(f"low {n} bits cover XCDs {sorted(set(low))} ({[low.count(x) for x in range(8)]} CUs per XCD)")
