@@ -557,14 +557,9 @@ def main():
         allv = [None] * world
         dist.all_gather_object(allv, final_ids.tolist())  # all jobs, before the one random fill of the read-out
         ranks_agree = all(a == allv[0] for a in allv) if tp > 1 else None
-    ar_probe, exposure = None, None
-    if use_dist and tp > 1:
-        ar_probe = model.collective_probe(L) if hasattr(model, "collective_probe") else None
-        if hasattr(model, "exchange_exposure_probe") and args.config in (0, 1, 4):
-            # the conditional forward of one step (batch = the step's jobs) with and without its 2 x n_layers exchanges
-            exposure = model.exchange_exposure_probe(wl["cpu"]["ids"].repeat(wl["images_per_step"], 1).to(dev))
+    # the timed region's own verdict FIRST: a hand-off of the exchange that timed out during the measurement voids the images
     comm_error = None
-    if getattr(model, "_comm_in_library", False):  # a hand-off of the pull transport timed out: the images are void
+    if getattr(model, "_comm_in_library", False):
         comm_error = model.comm_status()["error"]
         if use_dist:
             ce = torch.tensor([comm_error], device=dev, dtype=torch.int32)
@@ -572,6 +567,17 @@ def main():
             comm_error = int(ce.item())
         if comm_error:
             raise SystemExit(f"tensor-parallel exchange reported error {comm_error} (a peer never arrived): no benchmark line")
+    # ... then the stand-alone probes (outside the timed region).  A hand-off that times out inside a probe is recorded in the
+    # line (`probe_error`); it does not take the measurement away.  (An exception on ONE rank still ends the job: swallowing it
+    # would leave the other ranks waiting in the next collective.)
+    ar_probe, exposure, probe_error = None, None, None
+    if use_dist and tp > 1:
+        ar_probe = model.collective_probe(L) if hasattr(model, "collective_probe") else None
+        if hasattr(model, "exchange_exposure_probe") and args.config in (0, 1, 4):
+            # the conditional forward of one step (batch = the step's jobs) with and without its 2 x n_layers exchanges
+            exposure = model.exchange_exposure_probe(wl["cpu"]["ids"].repeat(wl["images_per_step"], 1).to(dev))
+        if getattr(model, "_comm_in_library", False) and model.comm_status()["error"]:
+            probe_error = "a hand-off timed out inside a stand-alone probe (after the timed region)"
     lprobe = None
     if (args.launch_probe or args.scaling == "strong") and "launch_probe" in wl:
         barrier()
@@ -629,7 +635,7 @@ def main():
                        "launched_by": ("bench.py self-launch -> torch.distributed.run" if os.environ.get("MMADA_BENCH_SELF_LAUNCHED")
                                        else "torch.distributed.run" if "RANK" in os.environ else "single process"),
                        "tp_comm_error": comm_error, "launch_probe": lprobe,
-                       "allreduce_probe": ar_probe,
+                       "allreduce_probe": ar_probe, "probe_error": probe_error,
                        "exposed_exchange_ms_per_forward": exposure["exposed_exchange_ms_per_forward"] if exposure else None,
                        "exchange_exposure_probe": exposure,
                        "rocm_smi_during_run": smi.summary() if smi else None,

@@ -539,10 +539,14 @@ class LLaDAForMultiModalGeneration:
         out = {"transport": self.tp_collective, "rows": B * L, "bytes": nbytes, "ms": ms,
                "busbw_GBps": 2.0 * (tp - 1) / tp * nbytes / (ms * 1e-3) / 1e9, "exchanges_per_forward": 2 * self.config.n_layers,
                "status": self.comm_status()}
-        if self.tp_collective in ("pull", "copy"):   # the other data path over the same mapped buffers, for comparison
+        # the other data path over the same mapped buffers, for comparison: OPT-IN (MMADA_TP_PROBE_COPY=1) — it exercises a
+        # transport the run did not select; a first multi-GPU session should ask for it explicitly
+        if self.tp_collective in ("pull", "copy") and os.environ.get("MMADA_TP_PROBE_COPY", "0") == "1":
             other, mode_other, mode_back = ("copy", 4, 1) if self.tp_collective == "pull" else ("pull", 1, 4)
-            abi.check(self._lib.mmada_comm_set_mode(self._handle, mode_other), "mmada_comm_set_mode")
+            # a comparison only: a data path that fails HERE (first contact with real multi-GPU hardware) must not take the
+            # benchmark line of the transport in use with it — record the error and go on
             try:
+                abi.check(self._lib.mmada_comm_set_mode(self._handle, mode_other), "mmada_comm_set_mode")
                 for _ in range(3):
                     abi.check(self._lib.mmada_comm_exchange(self._handle, w.data_ptr(), st), "mmada_comm_exchange")
                 torch.cuda.synchronize()
@@ -551,9 +555,13 @@ class LLaDAForMultiModalGeneration:
                     abi.check(self._lib.mmada_comm_exchange(self._handle, w.data_ptr(), st), "mmada_comm_exchange")
                 torch.cuda.synchronize()
                 ms3 = (time.perf_counter() - t0) / iters * 1e3
-                out[other] = {"ms": ms3, "busbw_GBps": 2.0 * (tp - 1) / tp * nbytes / (ms3 * 1e-3) / 1e9}
+                out[other] = {"ms": ms3, "busbw_GBps": 2.0 * (tp - 1) / tp * nbytes / (ms3 * 1e-3) / 1e9,
+                              "error_flag": self.comm_status()["error"]}
+            except Exception as e:   # noqa: BLE001
+                out[other] = {"error": str(e)[:300]}
             finally:
                 abi.check(self._lib.mmada_comm_set_mode(self._handle, mode_back), "mmada_comm_set_mode")
+                self._lib.mmada_comm_set_timeout(self._handle, 0.0)   # clears a sticky error the comparison may have left
         if getattr(self, "_rccl_also", False) and self.tp_collective in ("pull", "copy"):   # the same exchange over RCCL, for comparison
             abi.check(self._lib.mmada_comm_set_mode(self._handle, 2), "mmada_comm_set_mode")
             try:
