@@ -153,6 +153,8 @@ struct ReduceArgs {
     int size, rank;
     int nsrc;              // pull: = size (source j = rank j's partial, the own one read locally); RCCL: 1 (pre-summed rows)
     const bf16_t* presum;  // RCCL: [r1 - r0, d] rows already summed over ranks (row 0 = global row r0)
+    int src_row0[TP_MAX];  // row of source j's buffer that holds stream row 0 of this launch: 0 for a peer's whole partial buffer
+                           // (pull), r0 for a staged slice whose first row is this rank's first owned row (copy transport)
     const bf16_t* part;    // this rank's own partial [*, d]
     bf16_t* x;             // residual stream [*, d]: rows [r0, r1) are this rank's, updated in place
     const bf16_t* w;       // RMSNorm weight [d]
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void tp_reduce_norm_kernel(ReduceArgs a) {
                 u32x4 pv[TP];
 #pragma unroll
                 for (int j = 0; j < TP; ++j)  // p.part[rank] is this rank's own buffer: one uniform load form, no branch
-                    pv[j] = load_sys16(a.p.part[j], ((uint32_t)m * (uint32_t)a.d + c * 8) * 2u);
+                    pv[j] = load_sys16(a.p.part[j], ((uint32_t)(m - a.src_row0[j]) * (uint32_t)a.d + c * 8) * 2u);
 #pragma unroll
                 for (int j = 0; j < TP; ++j)  // rank order: the sum is the same on whichever rank owns the row
 #pragma unroll
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256) void tp_reduce_norm_kernel(ReduceArgs a) {
             } else {
                 for (int j = 0; j < a.size; ++j) {
                     const u32x4 v = (j == a.rank) ? ((const u32x4*)(a.part + (size_t)m * a.d))[c]
-                                                  : load_sys16(a.p.part[j], ((uint32_t)m * (uint32_t)a.d + c * 8) * 2u);
+                                                  : load_sys16(a.p.part[j], ((uint32_t)(m - a.src_row0[j]) * (uint32_t)a.d + c * 8) * 2u);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         acc[2 * e] += __uint_as_float(v[e] << 16);
@@ -394,8 +396,8 @@ int exchange(mmada_handle* h, const Slice& sl, const bf16_t* norm_w, hipStream_t
     }
     if (c->mode == 4) {
         if (signal_wait(c, s)) return 1;  // every rank's partial of this chunk is complete
-        // the tp - 1 peer slices of MY rows -> local staging, by the copy engines; the kernel then sums local operands.  The
-        // source pointer of peer j is shifted so that the kernel's row index m addresses staging row m - r0.
+        // the tp - 1 peer slices of MY rows -> local staging, by the copy engines; the kernel then sums local operands
+        // (src_row0[j] = r0: staging row 0 of peer j is stream row r0)
         ReduceArgs b = a;
         b.nsrc = c->size;
         if (own > 0) {
@@ -403,7 +405,8 @@ int exchange(mmada_handle* h, const Slice& sl, const bf16_t* norm_w, hipStream_t
                 if (j == c->rank) { b.p.part[j] = c->part; continue; }
                 bf16_t* dst = c->stage + (size_t)j * c->stage_stride;
                 MM_CHECK_HIP(hipMemcpyAsync(dst, c->peers.part[j] + (size_t)sl.r0 * d, (size_t)own * d * 2, hipMemcpyDefault, s));
-                b.p.part[j] = dst - (size_t)sl.r0 * d;
+                b.p.part[j] = dst;
+                b.src_row0[j] = sl.r0;
             }
             const dim3 grid((own + 3) / 4), blk(256);
             switch (c->size) {
