@@ -29,6 +29,8 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* The library is built with -fvisibility=hidden: only what this header declares is exported. */
+#pragma GCC visibility push(default)
 
 typedef struct mmada_handle mmada_handle;
 
@@ -337,8 +339,8 @@ int mmada_profile_end(mmada_handle* h, int32_t* count_out /*[5]*/, double* ms_ou
  * so that sweeps and A/B tests can pin one.
  *   "gemm_config"    -1 automatic (default: the cost model of csrc/gemm.hip); 0..3 the 8-phase kernel's tile configuration
  *                    (320x256, 256x256, 160x256, 320x128); 1000 + BM the 16-wave kernel with that row-tile height
- *   "attention_form" -1 automatic (default: MMADA_ATTN_FORM or 1); 0 the round-2 issue order; 1 software-pipelined matrix
- *                    blocks (fragments prefetched in registers, pinned issue order)
+ *   "attention_form" -1 automatic (default: MMADA_ATTN_FORM or 1); 0 every wave of a workgroup in the plain order
+ *                    { S, soft-max, P·V }; 1 waves 4-7 accumulate P·V one key tile late (bit-identical output)
  *   "gemm_silu_lut"  1 (default): the 8-phase SwiGLU epilogue reads SiLU of the bf16 gate value from a 10-KiB table in the LDS (filled on
  *                    the device by the function it replaces; untabulated values are evaluated); 0: always evaluate
  *   "gemm_short_tiles" 1 (default): the 320-row configurations use a row-tile pitch of 304 when ntm - 1 tiles of 304 rows and
@@ -466,6 +468,7 @@ int mmada_rmsnorm(const void* x, const void* w, void* out, int rows, int d, floa
 int mmada_sdpa(mmada_handle* h, const void* q, const void* k, const void* v, void* out, int B, int H, int Hkv, int L,
                void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

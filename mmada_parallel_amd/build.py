@@ -4,7 +4,8 @@ hipcc cross-compiles without a GPU; the resulting .so sits next to this file so 
 Translation units are compiled in parallel (one hipcc per .hip, objects under csrc/_obj/) and linked once.
 
 `verify=True` (what __graft_entry__.build() passes) also checks the COMPILED code of the hand-scheduled kernels with
-tools/isa_check.py and fails the build on a violation: the LDS-DMA requests of gemm8.hip / attention.hip are
+tools/isa_check.py (an assembly listing made with the SAME flags as the objects) and fails the build on a violation — removing
+the objects, so that a later unverified build cannot link them: the LDS-DMA requests of gemm8.hip / attention.hip are
 asm statements that write M0 themselves, which is only correct while hipcc keeps nothing live in M0 across them and while
 nothing but LDS-DMA sits in the vector-memory queue in front of a counted wait — properties of the compiler's output, not
 of the source, so a compiler upgrade must not be able to break them silently.
@@ -24,8 +25,12 @@ OBJ = os.path.join(CSRC, "_obj")
 LIB_NAME = "libmmada_mi355x.so"
 LIB_PATH = os.path.join(HERE, LIB_NAME)
 SOURCES = ["gemm.hip", "gemm8.hip", "attention.hip", "elementwise.hip", "sampler.hip", "vq_decoder.hip", "graph.hip", "tp_comm.hip", "probe.hip", "api.hip"]
-HEADERS = ["common.h", "kernels.h", "gemm_epilogue.h", "handle.h", "attention.h", os.path.join("..", "..", "include", "mmada_mi355x.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+HEADERS = ["exports.map", "common.h", "kernels.h", "gemm_epilogue.h", "handle.h", "attention.h", os.path.join("..", "..", "include", "mmada_mi355x.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-fvisibility-inlines-hidden", "-Wno-unused-result"]
+# per-unit flags.  attention: hipcc's SLP vectoriser pairs the fp32 row-sum adds and rescale multiplies into v_pk_*_f32, which
+# cost more issue time beside MFMAs than the two scalar operations they replace (MI355X guide, per-instruction constants);
+# without NaN semantics fmaxf() on MFMA results needs no canonicalising v_max x,x and nests into v_max3_f32
+UNIT_FLAGS = {"attention.hip": ["-fno-slp-vectorize", "-fno-honor-nans"]}
 
 
 def _hipcc() -> str:
@@ -60,7 +65,7 @@ def compile_objects(out_dir: str, extra_flags=(), force: bool = False, verbose: 
         objs.append(obj)
         sp = os.path.join(CSRC, src)
         if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(hdr_t, os.path.getmtime(sp)):
-            todo.append([_hipcc(), *FLAGS, *extra_flags, "-c", sp, "-o", obj])
+            todo.append([_hipcc(), *FLAGS, *UNIT_FLAGS.get(src, []), *extra_flags, "-c", sp, "-o", obj])
     if verbose:
         for c in todo:
             print(" ".join(c))
@@ -95,9 +100,17 @@ def build(force: bool = False, verbose: bool = False, verify: bool = False) -> s
     with ThreadPoolExecutor(max_workers=2) as ex:
         chk = ex.submit(verify_isa) if verify else None
         objs = compile_objects(OBJ, force=force, verbose=verbose)
-        _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB_PATH + ".tmp"])
+        _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(CSRC, "exports.map"), *objs,
+              "-o", LIB_PATH + ".tmp"])
         if chk is not None:
-            chk.result()
+            try:
+                chk.result()
+            except Exception:
+                # the checked code IS what these objects hold (same flags): do not leave them for a later unverified link
+                for o in objs + [LIB_PATH + ".tmp"]:
+                    if os.path.exists(o):
+                        os.remove(o)
+                raise
     os.replace(LIB_PATH + ".tmp", LIB_PATH)
     return LIB_PATH
 

@@ -158,9 +158,9 @@ static int apply_carve(mmada_handle* h, int B, int L, hipStream_t s) {
     h->k = (bf16_t*)(h->ws + c.k); h->vT = (bf16_t*)(h->ws + c.vT); h->xg = (bf16_t*)(h->ws + c.xg);
     h->rows_all = (int32_t*)(h->ws + c.rows);
     h->posmap = (int32_t*)(h->ws + c.posmap);
-    // vT columns never written by the QKV epilogue (keys >= Lp; the key order inside a 16-key group is permuted, so
-    // start at the last group boundary) are multiplied by P == 0: keep them finite
-    const int z0 = c.Lp & ~15;
+    // vT columns never written by the QKV epilogue (keys >= Lp; the key order inside a 32-key block is permuted, so
+    // start at the last block boundary) are multiplied by P == 0: keep them finite
+    const int z0 = c.Lp & ~31;
     if (c.Lkv > z0)
         MM_CHECK_HIP(hipMemset2DAsync(h->vT + z0, (size_t)c.Lkv * 2, 0, (size_t)(c.Lkv - z0) * 2,
                                       (size_t)B * h->hkv_l * 128, s));

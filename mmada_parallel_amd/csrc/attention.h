@@ -1,6 +1,6 @@
-// attention.h — tile constants, launch arguments, single-instruction maxima and LDS addressing of the attention kernels of
-// attention.hip (4 waves x 32 query rows).  (Round 4's attention64.hip — 64 query rows per wave, one wave per SIMD, a hand-owned
-// accumulator file: bit-identical and not faster — was removed in round 5; DESIGN.md §3 keeps what it taught.)
+// attention.h — tile constants, launch arguments and LDS addressing of the attention kernel (attention.hip: 8 waves per
+// workgroup, 0-3 groups of 16 query rows per wave, v_mfma_f32_16x16x32_bf16).  Rounds 2-5 shipped a 4-wave x 32-row kernel on
+// v_mfma_f32_32x32x16_bf16 (and, in round 4, a 64-row one-wave-per-SIMD form); profiles/HISTORY.md keeps what they taught.
 #pragma once
 #include <cstdlib>
 #include <type_traits>
@@ -9,27 +9,11 @@
 
 namespace attn_detail {
 
-constexpr int QB = 128;  // query rows per workgroup
 constexpr int KB = 64;   // keys per tile
-constexpr int TILE_BYTES = KB * 128 * 2;  // 16 KiB (K tile == vT tile)
-constexpr int ATT_LDS = 4 * TILE_BYTES;   // 2 stages x (K + vT)
 constexpr float DEFER_LOG2 = 4.0f;
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
-
-// 3-input / 2-input fp32 max as single instructions: hipcc wraps fmaxf() on MFMA outputs in canonicalising
-// v_max_f32 x,x (one extra VALU op per score); scores are never signalling NaNs here.
-MM_DEVICE float max3f(float a, float b, float c) {
-    float r;
-    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-MM_DEVICE float fmax_nc(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 
 struct AttnArgs {
     const bf16_t* q;
@@ -40,7 +24,9 @@ struct AttnArgs {
     int q_begin;  // first query row (multiple of 32); output row of query r is b*out_rows_per_batch + r - q_begin
     int Lq_alloc; // rows per (batch, head) of q: Lkv, or the compact length of a cache step's queries
     float scale_log2e;
-    int xcd_pairs, nq;  // XCD-aware 1-D grid: (batch, head) pairs per XCD and query tiles per pair (0: plain 3-D grid)
+    int xcd_pairs;      // XCD-aware grid: (batch, head) pairs per XCD (0: pair-major grid)
+    int groups, chunks; // 16-row query groups per (batch, head) pair and workgroups the pair is cut into
+    int plain_order;    // 1: no late waves (attention form 0)
 };
 
 // The kernel owns its whole LDS allocation and has no static __shared__ object: the dynamic segment starts at LDS address 0

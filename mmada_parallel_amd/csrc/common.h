@@ -54,12 +54,14 @@ MM_DEVICE int xcd_remap(int bid, int nwg) {
     return base + idx;
 }
 
-// Position of key l inside the K-major V buffer: the four 4-key chunks of every 16-key group are stored in the
-// order [0, 2, 1, 3], which is the key order of a 32x32 MFMA accumulator column (key = (r&3) + 8*(r>>2) + 4*hi),
-// so the attention PV operand is one 16-byte read (attention.hip).
+// Position of key l inside the K-major V buffer: inside every 32-key block the eight 4-key chunks are stored in the order
+// [0, 4, 1, 5, 2, 6, 3, 7] — position 8g+j holds key 4g+j (j < 4) or key 16+4g+(j-4), the eight keys lane quad g of a wave
+// holds of two neighbouring 16-key score tiles (v_mfma_f32_16x16x32_bf16: lane (quad g, column q) = keys 4g..4g+3 of query q),
+// so P goes from the score accumulators into the P·V operand without leaving its lane and the attention PV operand is one
+// 16-byte read (attention.hip).  (Rounds 1-5: 16-key blocks in the key order of a 32x32 accumulator column.)
 MM_DEVICE int vt_key_pos(int l) {
-    const int c = (l >> 2) & 3;
-    return (l & ~12) | ((c & 1) << 3) | ((c >> 1) << 2);
+    const int c = (l >> 2) & 7;
+    return (l & ~28) | ((c & 3) << 3) | ((c >> 2) << 2);
 }
 
 #define MM_CHECK_HIP(expr)                                                                 \

@@ -8,6 +8,7 @@
 // random bf16 data held in registers, 16 independent accumulators per wave.  Its rate, measured right after the timed
 // region of a bench run while the chip is still warm, is the roof a real kernel could at best approach on this part at
 // that moment; `roofline.frac` stays quoted against the 2.5 PFLOP/s datasheet peak.
+#include "../../include/mmada_mi355x.h"
 #include "kernels.h"
 
 namespace {

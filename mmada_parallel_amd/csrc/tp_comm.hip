@@ -691,7 +691,7 @@ int mmada_comm_create(mmada_handle* h, int max_rows, void* export_out) {
     c->data_fine = fine_data;
     MM_CHECK_HIP(hipMalloc(&c->rs_tmp, ((size_t)(max_rows + c->size - 1) / c->size + 16) * c->d * 2));
     c->stage_stride = ((size_t)(max_rows + c->size - 1) / c->size + 16) * c->d;   // one owner slice of the largest chunk
-    MM_CHECK_HIP(hipMalloc(&c->stage, c->stage_stride * c->size * 2));
+    c->stage = nullptr;  // the copy transport's landing zone: allocated by the first mmada_comm_set_mode(4)
     MM_CHECK_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
     MM_CHECK_HIP(hipEventCreateWithFlags(&c->ev_out, hipEventDisableTiming));
     MM_CHECK_HIP(alloc_pub((void**)&c->stats_pub, (size_t)STAT_ROWS * sizeof(TextStat), true, nullptr));
@@ -826,6 +826,7 @@ int mmada_comm_set_mode(mmada_handle* h, int mode) {
     if (mode == 3 && c->mode == 0) return mm_fail("mmada_comm_set_mode: connect a transport before the no-exchange diagnostic");
     if (mode == 4 && !c->peers.ctr[other]) return mm_fail("mmada_comm_set_mode: the copy transport needs the mapped peer buffers (connect_ipc / connect_local)");
     if (mode < 1 || mode > 4) return mm_fail("mmada_comm_set_mode: mode must be 1 (pull), 2 (RCCL), 3 (diagnostic: no exchange) or 4 (copy engines)");
+    if (mode == 4 && !c->stage) MM_CHECK_HIP(hipMalloc(&c->stage, c->stage_stride * c->size * 2));  // pull / RCCL users never pay for it
     c->mode = mode;
     return 0;
 }
@@ -854,17 +855,29 @@ int mmada_comm_set_partition(mmada_handle* h, int exchange_cus) {
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
     if (c->s_cmp) { (void)hipStreamDestroy(c->s_cmp); c->s_cmp = nullptr; }
     if (c->sc) { (void)hipStreamDestroy(c->sc); c->sc = nullptr; }
-    c->part_cus = exchange_cus;
-    if (exchange_cus == 0) {
-        MM_CHECK_HIP(hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, hi));
-        return 0;
-    }
+    c->part_cus = 0;
+    // whatever happens below, the exchange keeps a usable stream: the un-partitioned one (high priority, non-blocking)
+    MM_CHECK_HIP(hipStreamCreateWithPriority(&c->sc, hipStreamNonBlocking, hi));
+    if (exchange_cus == 0) return 0;
     const int words = (ncu + 31) / 32;
     uint32_t mx[16] = {}, mc[16] = {};
     if (words > 16) return mm_fail("mmada_comm_set_partition: %d CUs exceed the mask buffer", ncu);
     for (int i = 0; i < ncu; ++i) (i < exchange_cus ? mx : mc)[i / 32] |= 1u << (i % 32);
-    MM_CHECK_HIP(hipExtStreamCreateWithCUMask(&c->sc, words, mx));
-    MM_CHECK_HIP(hipExtStreamCreateWithCUMask(&c->s_cmp, words, mc));
+    // hipExtStreamCreateWithCUMask takes no flags: both masked streams are BLOCKING, default-priority streams, i.e. implicitly
+    // ordered against the legacy null stream.  A caller that drives the forward on the null stream (torch's default stream on
+    // ROCm) therefore serialises with them and sees no overlap; pass a non-default stream while a partition is active
+    // (bench.py and the probes do).  The partition is reported (mmada_comm_partition) only once BOTH streams exist.
+    hipStream_t sx = nullptr, scmp = nullptr;
+    hipError_t e = hipExtStreamCreateWithCUMask(&sx, words, mx);
+    if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&scmp, words, mc);
+    if (e != hipSuccess) {
+        if (sx) (void)hipStreamDestroy(sx);
+        return mm_fail("mmada_comm_set_partition: hipExtStreamCreateWithCUMask: %s (no partition in effect)", hipGetErrorString(e));
+    }
+    (void)hipStreamDestroy(c->sc);
+    c->sc = sx;
+    c->s_cmp = scmp;
+    c->part_cus = exchange_cus;
     return 0;
 }
 int mmada_comm_partition(mmada_handle* h) { return h && h->tp ? h->tp->part_cus : 0; }

@@ -338,8 +338,8 @@ class LLaDAForMultiModalGeneration:
             n *= v
         off = p.value - self._ws.data_ptr()
         t = self._ws[off:off + n].view(torch.bfloat16).view(*shape)
-        if which == 3:  # undo the [0,2,1,3] chunk order of every 16-key group (csrc/common.h vt_key_pos)
-            t = t.reshape(B, hkv, 128, lkv.value // 16, 4, 4)[..., [0, 2, 1, 3], :].reshape(B, hkv, 128, lkv.value)
+        if which == 3:  # undo the [0,4,1,5,2,6,3,7] chunk order of every 32-key block (csrc/common.h vt_key_pos)
+            t = t.reshape(B, hkv, 128, lkv.value // 32, 8, 4)[..., [0, 2, 4, 6, 1, 3, 5, 7], :].reshape(B, hkv, 128, lkv.value)
         return t
 
     def forward(self, input_ids=None, labels=None, infer=False, use_cache=False, to_compute_mask=None, cat="", **_):
@@ -354,14 +354,16 @@ class LLaDAForMultiModalGeneration:
         if to_compute_mask is not None and not use_cache:
             raise ValueError("to_compute_mask needs use_cache=True (the reference only gathers the tokens then, "
                              "model/modeling_llada.py:1244-1245)")
-        if use_cache and self.tp_size == 1:
+        if use_cache and (self.tp_size == 1 or self._comm_in_library):
+            # also under tensor parallelism when the exchange runs in the library (init_tp_comm): every rank caches its heads
             self.forward_cached(input_ids, to_compute_mask=to_compute_mask, cat=cat)
             B, L = self._cache[cat].shape
             rows = torch.arange(B * L, dtype=torch.int32, device=self.device)
             return CausalLMOutputLite(logits=self.cache_head_rows(cat, rows, 0, self.vocab).view(B, L, self.vocab))
         if to_compute_mask is not None:
-            raise NotImplementedError("the dLLM cache path is single-rank (tp_size == 1)")
-        # tensor parallel + use_cache without a mask: every row is recomputed and nothing is kept (same logits)
+            raise NotImplementedError("the dLLM cache under tensor parallelism needs the library's exchange (init_tp_comm); "
+                                      "the host all-reduce fallback recomputes every row")
+        # host all-reduce fallback + use_cache without a mask: every row is recomputed and nothing is kept (same logits)
         self.forward_body(input_ids)
         B, L = self._shape
         rows = torch.arange(B * L, dtype=torch.int32, device=self.device)
@@ -545,6 +547,8 @@ class LLaDAForMultiModalGeneration:
             other, mode_other, mode_back = ("copy", 4, 1) if self.tp_collective == "pull" else ("pull", 1, 4)
             # a comparison only: a data path that fails HERE (first contact with real multi-GPU hardware) must not take the
             # benchmark line of the transport in use with it — record the error and go on
+            err_in_use = out["status"]["error"]   # what the transport IN USE left behind: recorded above, never erased below
+            ok = 1
             try:
                 abi.check(self._lib.mmada_comm_set_mode(self._handle, mode_other), "mmada_comm_set_mode")
                 for _ in range(3):
@@ -557,11 +561,21 @@ class LLaDAForMultiModalGeneration:
                 ms3 = (time.perf_counter() - t0) / iters * 1e3
                 out[other] = {"ms": ms3, "busbw_GBps": 2.0 * (tp - 1) / tp * nbytes / (ms3 * 1e-3) / 1e9,
                               "error_flag": self.comm_status()["error"]}
+                ok = int(out[other]["error_flag"] == 0)
             except Exception as e:   # noqa: BLE001
                 out[other] = {"error": str(e)[:300]}
+                ok = 0
             finally:
                 abi.check(self._lib.mmada_comm_set_mode(self._handle, mode_back), "mmada_comm_set_mode")
-                self._lib.mmada_comm_set_timeout(self._handle, 0.0)   # clears a sticky error the comparison may have left
+                if err_in_use == 0:   # only a flag the COMPARISON raised is cleared; an earlier one stays for bench.py to report
+                    self._lib.mmada_comm_set_timeout(self._handle, 0.0)
+            # a rank that failed stopped issuing exchanges while its peers went on: agree on the outcome before anything else
+            # uses the group (the comparison's figure is only meaningful when every rank completed it)
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                out[other]["all_ranks_ok"] = bool(int(flag.item()))
         if getattr(self, "_rccl_also", False) and self.tp_collective in ("pull", "copy"):   # the same exchange over RCCL, for comparison
             abi.check(self._lib.mmada_comm_set_mode(self._handle, 2), "mmada_comm_set_mode")
             try:

@@ -27,6 +27,18 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(abi.SIGNATURES) == syms, "abi.py and the header disagree on the symbol list"
 
 
+def test_nothing_but_the_header_is_exported():
+    """-fvisibility=hidden, the header's visibility pragma and the linker version script (csrc/exports.map): the dynamic symbol table holds the declared mmada_* entry points and
+    no C++ internals (round 5 exported 44 mangled launchers)."""
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", build.build()], capture_output=True, text=True, check=True).stdout
+    names = [ln.split()[-1] for ln in out.splitlines() if ln.strip()]
+    mangled = [n for n in names if n.startswith("_Z")]
+    assert not mangled, f"{len(mangled)} C++ symbols exported, e.g. {mangled[:3]}"
+    assert sorted(names) == header_symbols(), sorted(set(names) ^ set(header_symbols()))
+
+
 def test_argument_errors_are_reported_without_a_gpu():
     lib = abi.lib()
     assert lib.mmada_create(None, None, None) != 0

@@ -227,9 +227,10 @@ def test_gemm_configurations_are_bit_identical(M, N, K):
 @pytest.mark.parametrize("B,H,Hkv,L", [(1, 2, 2, 70), (2, 2, 1, 333), (1, 8, 8, 1000), (1, 2, 2, 64), (1, 1, 1, 1), (1, 8, 8, 2438),
                                        (2, 8, 4, 2438), (1, 2, 2, 129), (1, 2, 2, 192)])
 def test_attention_forms_are_bit_identical(handle, B, H, Hkv, L):
-    """The pipelined form of the attention kernel (round 3: fragments prefetched three k-steps ahead with a pinned issue order,
-    the four O accumulators interleaved, LDS-DMA pieces spread over the S block) does per wave exactly the arithmetic of the
-    round-2 kernel, in the same order: identical bits, for odd and even key-tile counts and a forced rescale."""
+    """Form 1 of the attention kernel (waves 4-7 of a workgroup accumulate P·V one key tile late, so that a wave's soft-max sits
+    beside its SIMD partner's matrix phase) does per query row exactly the arithmetic of form 0 (every wave in the plain order),
+    in the same order: identical bits, for odd and even key-tile counts, partial groups, grouped heads and a forced rescale.
+    The shapes also cover 1-3 query groups per wave and workgroup counts per head from 1 to 8 (attention_chunks)."""
     torch.manual_seed(1000 + L)
     q = torch.randn(B, H, L, 128).to(torch.bfloat16).to(DEV)
     k = torch.randn(B, Hkv, L, 128).to(torch.bfloat16).to(DEV)

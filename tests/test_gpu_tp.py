@@ -319,6 +319,13 @@ def test_dllm_cache_under_tensor_parallelism(tiny_tp1):
         scale = ref.abs().max().item()
         print(f"dLLM cache, TP=2 vs TP=1, {what}: max {err.max().item() / scale:.3e} mean {err.mean().item() / scale:.3e}")
         assert err.max().item() < 4e-2 * scale and err.mean().item() < 6e-3 * scale
+    # the reference's keyword contract (model/modeling_llada.py:1468-1493) routes to the same branch under TP:
+    # model(ids, infer=True, use_cache=True, to_compute_mask=m, cat=c).logits is the whole logit cache
+    prime_call = _each(ranks, streams, lambda m: m(ids0, infer=True, use_cache=True, cat="c2").logits.clone())
+    step_call = _each(ranks, streams, lambda m: m(ids1, infer=True, use_cache=True, to_compute_mask=m1, cat="c2").logits.clone())
+    assert step_call[0].shape == (B, L, ranks[0].vocab) and torch.equal(step_call[0], step_call[1])
+    assert torch.equal(prime_call[0].reshape(B * L, -1)[:, lo:hi], primed[0]), "forward(use_cache=True) under TP primes the slot"
+    assert torch.equal(step_call[0].reshape(B * L, -1)[:, lo:hi], step[0]), "forward(use_cache=True, to_compute_mask=...) under TP"
     for m in ranks:
         assert m.comm_status()["error"] == 0
         m.empty_cache()

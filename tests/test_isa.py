@@ -25,10 +25,11 @@ def test_gemm8_counted_waits_see_only_lds_dma():
 
 
 def test_attention_matrix_blocks_are_software_pipelined():
-    """Also: no spills, no static LDS, and the per-tile half-row exchange on the VALU (v_permlane32_swap, no ds_bpermute)."""
+    """Also: no spills, no static LDS, no packed fp32 VALU, no canonicalising maxima, and no compiler-counted vmcnt wait inside a
+    tile loop (the LDS-DMA requests of the next tile share that queue)."""
     report, errors = isa_check.check_attention()
     assert not errors, "\n".join(errors)
-    assert report and report[0][2] >= 64
+    assert report and report[0][2] >= 6 * 32   # S and P·V blocks of the six (groups, order) instantiations
 
 
 def test_tp_pull_transport_uses_16_byte_system_scope_loads():

@@ -11,8 +11,8 @@ hand-written wait must be `vmcnt(0)` (which is exact whatever is queued); a coun
 Also checked: no static LDS (the kernel forms LDS addresses from integers, i.e. assumes its dynamic segment starts at 0),
 and every kernel really uses the LDS-DMA saddr form.
 
-Epilogues of the 8-phase GEMM (STORE / RESID / SwiGLU builds): 16-byte stores only, fed by v_permlane16_swap.  Attention: the
-per-tile half-row maximum is exchanged with v_permlane32_swap (no ds_bpermute inside the loop).
+Epilogues of the 8-phase GEMM (STORE / RESID / SwiGLU builds): 16-byte stores only, fed by v_permlane16_swap.  Attention
+(check_attention): pipelined fragment reads, no spills, no packed fp32 VALU, no compiler-counted vmcnt wait inside a tile loop.
 
 The tensor-parallel pull transport (csrc/tp_comm.hip) must read remote memory with ONE 16-byte system-scope load per
 16 bytes (`global_load_dwordx4 ... sc0 sc1`), never as two 8-byte halves (each would use half of every 64-B fabric
@@ -36,9 +36,12 @@ def hipcc():
 
 
 def device_asm(src):
-    """gfx950 assembly text of one translation unit."""
-    out = subprocess.run([hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-I", CSRC,
-                          os.path.join(CSRC, src), "-o", "-"], capture_output=True, text=True)
+    """gfx950 assembly text of one translation unit, compiled with the flags of the shipped object (build.FLAGS + UNIT_FLAGS)."""
+    sys.path.insert(0, ROOT)
+    from mmada_parallel_amd import build as _build
+    flags = [f for f in _build.FLAGS if f != "-fPIC"] + ["-fPIC"] + _build.UNIT_FLAGS.get(src, [])
+    out = subprocess.run([hipcc(), *flags, "--cuda-device-only", "-S", "-I", CSRC, os.path.join(CSRC, src), "-o", "-"],
+                         capture_output=True, text=True)
     if out.returncode != 0:
         raise RuntimeError(out.stderr)
     return out.stdout
@@ -230,13 +233,17 @@ def check_gemm8(asm=None):
 
 
 def check_attention(asm=None):
-    """The pipelined attention kernel: its matrix blocks must really be software-pipelined (counted lgkmcnt waits, not a
-    full drain in front of every MFMA pair), it forms LDS addresses from integers (no static LDS) and must not spill."""
+    """The attention kernel (csrc/attention.hip, attn16_kernel): its matrix blocks must really be software-pipelined (counted
+    lgkmcnt waits, not a full drain in front of every MFMA group), it forms LDS addresses from integers (no static LDS), must not
+    spill, keeps its fp32 row sums / rescales as single instructions (no v_pk_*_f32: built with -fno-slp-vectorize) and — the
+    hazard found in round 6 — carries no compiler-made `s_waitcnt vmcnt(N > 0)` inside a loop: hipcc counts only the loads it
+    knows, the LDS-DMA requests of the next tile are in the same queue, so such a wait (the Q fragment loads, if their first
+    use sinks into the loop) would stall every tile until the DMA lands."""
     asm = asm or device_asm("attention.hip")
     body, meta = kernels(asm)
     report, errors = [], []
     for name, lines in body.items():
-        if "attn4p_fwd_kernel" not in name:
+        if "attn16_kernel" not in name:
             continue
         lds = int(meta.get(name, {}).get("group_segment_fixed_size", "0"))
         if lds != 0:
@@ -249,18 +256,25 @@ def check_attention(asm=None):
         n_saddr = sum(1 for ln in lines if re.search(r"global_load_lds_dwordx4\s+v\d+,\s*s\[", ln))
         if n_dma == 0 or n_saddr != n_dma:
             errors.append(f"{name}: {n_saddr} of {n_dma} LDS-DMA loads use the scalar-base form")
-        if counted < 12:
+        if counted < 48:
             errors.append(f"{name}: only {counted} counted lgkmcnt waits: the fragment prefetch was serialised by the compiler")
-        # the half-row maximum of every key tile is exchanged on the VALU (v_permlane32_swap); the only ds_bpermute left is
-        # the one of the final row sum, outside the loop
-        n_swap = sum(1 for ln in lines if ln.strip().startswith("v_permlane32_swap"))
-        n_bperm = sum(1 for ln in lines if ln.strip().startswith("ds_bpermute"))
-        if n_swap < 1 or n_bperm > 1:
-            errors.append(f"{name}: {n_swap} v_permlane32_swap, {n_bperm} ds_bpermute (expected the per-tile exchange on the VALU)")
+        n_pk = sum(1 for ln in lines if re.match(r"\s*v_pk_(add|mul|fma)_f32", ln))
+        if n_pk:
+            errors.append(f"{name}: {n_pk} v_pk_*_f32 instructions (the unit must be built with -fno-slp-vectorize)")
+        n_canon = sum(1 for ln in lines if re.match(r"\s*v_max_f32_e32 (v\d+), (v\d+), \2\b", ln))
+        if n_canon:
+            errors.append(f"{name}: {n_canon} canonicalising v_max x,x (the unit must be built with -fno-honor-nans)")
+        in_loop = False
+        for ln in lines:
+            if re.match(r"^\.LBB\d+_\d+:", ln):
+                in_loop = "Loop Header" in ln or "in Loop:" in ln
+            m = re.match(r"\s*s_waitcnt .*vmcnt\((\d+)\)", ln)
+            if in_loop and m and int(m.group(1)) > 0:
+                errors.append(f"{name}: compiler-counted `{ln.strip()}` inside a tile loop (LDS-DMA shares that queue)")
         errors += check_m0(name, lines)
         report.append((name, n_dma, sum(1 for ln in lines if "v_mfma" in ln), counted))
     if not report:
-        errors.append("attn4p kernel not found")
+        errors.append("attn16_kernel not found")
     return report, errors
 
 
