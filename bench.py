@@ -266,6 +266,8 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
         T, N = job["text_end"] - job["text_start"], job["seq_len"]
         grid = int(round(N ** 0.5))
         state = {}
+        if args.temperature != 0:   # inference.py:164-167 creates a device generator when --seed != 0 (README: --seed 42)
+            state["generator"] = torch.Generator(device=dev).manual_seed(42)
         connect(model, 2 * B, L)
         # pixels in -> pixels out, as inference.py runs a job (:94-96,127,218-225): the input image is tokenised by the VQ
         # model before the sampler and the sampled codes are decoded after it.  The tokenizer is diffusers' VQModel in the
@@ -308,9 +310,10 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
             job_ids[:, in_pos] = codes + synth.TEXT_VOCAB
             vq, _, final = generate_ti2ti(model, job_ids, job["text_start"], job["text_end"], job["image_start"],
                                           job["seq_len"], job["newline_every"], text_steps=args.text_steps,
-                                          timesteps=args.timesteps, temperature=0.0, text_temperature=0.0,
+                                          timesteps=args.timesteps, temperature=args.temperature, text_temperature=0.0,
                                           cfg_scale=cfg_scale, cfg_img=4.0, uncon_text=job["uncon_text"],
-                                          uncon_image=job["uncon_image"], return_state=True)
+                                          uncon_image=job["uncon_image"], return_state=True,
+                                          generator=state.get("generator"))
             # decode_vq_to_image; the one position the schedule leaves masked is a random code in the reference (A.1)
             out_codes = (final[mine][:, out_pos] - synth.TEXT_VOCAB).clamp(0, CB - 1).view(-1, grid, grid).to(dev)
             ev[2].record()
@@ -353,7 +356,9 @@ def build_workload(args, cfgnum, model_cls_mod, dev, cfg, tp, world, rank):
                 f"temperature=0, L={L}, 64 forwards/image (the reference's CPU-runnable case, here on the GPU), pixels in -> "
                 "pixels out") if cfgnum == 0 else \
                ("BASELINE configs[1]: MMaDA-Parallel-A 8B, 512x512, timesteps=64, text_steps=128, cfg_img=4.0, "
-                "temperature=0, L=2438, 256 forwards/image, pixels in -> pixels out (VQ encode + decode inside the step)"
+                f"temperature={args.temperature:g}, L=2438, 256 forwards/image, pixels in -> pixels out (VQ encode + decode inside the step)"
+                + (" [SECONDARY LINE: the reference README's sampling settings (temperature 1.0, text_temperature 0, seed 42), not "
+                   "the parity configuration the headline is quoted on]" if args.temperature != 0 else "")
                 + (f"; STRONG scaling: one job over {tp} tensor-parallel rank(s)" if args.scaling == "strong" else "")) \
             if cfgnum == 1 else \
                (f"BASELINE configs[4] (single-GPU form): MMaDA-Parallel-A 8B editing, batch={B}, 512x512, cfg_scale=3.0 + "
@@ -472,6 +477,10 @@ def main():
     ap.add_argument("--launch-probe", action="store_true",
                     help="after the timed region: one image eager and one hipGraph-replayed with the host's per-step enqueue time "
                          "(always on with --scaling strong)")
+    ap.add_argument("--temperature", type=float, default=0.0, help="image sampling temperature: 0 (default) is the parity "
+                    "configuration the headline is quoted on; 1.0 is the reference README's setting (README.md:101-118: "
+                    "--temperature 1.0 --text_temperature 0 --cfg_scale 0 --cfg_img 4.0 --seed 42): torch.multinomial + gather + "
+                    "randn per image step, no step graph — a SECONDARY line, marked in config.sampling")
     ap.add_argument("--no-probe", action="store_true", help="skip the ~1 s attainable-MFMA probe after the timed region")
     ap.add_argument("--layers", type=int, default=None, help="debug only: fewer layers (marks the line reduced)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -613,6 +622,9 @@ def main():
             "scaling": "weak" if args.config == 1 and args.scaling == "weak" else "strong", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": wl["workload"] + (" [REDUCED DEBUG RUN]" if reduced else ""),
+                       "sampling": {"temperature": args.temperature, "text_temperature": 0.0,
+                                    "what": "parity configuration (temperature 0)" if args.temperature == 0 else
+                                    "reference README settings: torch.multinomial + gather + randn per image step, no step graph"},
                        "baseline_config_index": args.config,
                        "global_batch": wl["images_per_step"] * (world if tp == 1 and world > 1 else 1), "seq_len": L,
                        "parallelism": f"{args.parallelism}{world}",

@@ -229,7 +229,9 @@ MM_DEVICE void attn16_wave(const AttnArgs& a, const Wave16& w) {
     }
     if constexpr (LATE) pv(LDS_V0 + (vst == 0 ? 2 : vst - 1) * STAGE);
 
-    // ---- normalise and store: lane holds O[row][d = 16 dt + 4 quad + r] ----
+    // ---- normalise and store: lane holds O[row][d = 16 dt + 4 quad + r]; two neighbouring feature tiles are exchanged between
+    // lane quads (v_permlane16_swap) so that every lane stores 8 consecutive features = one 16-byte access (guide T21):
+    // quad 0 / 2: features 0-7 / 8-15 of the even tile, quad 1 / 3: of the odd tile ----
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         float l = l_run[g];
@@ -237,19 +239,20 @@ MM_DEVICE void attn16_wave(const AttnArgs& a, const Wave16& w) {
         l += __shfl_xor(l, 32, 64);
         const float inv = 1.0f / l;
         const int row = w.row0 + g * 16 + qi;
-        if (row < a.Lq_rows) {
-            bf16_t* orow = w.out + (size_t)(row - a.q_begin) * a.ld_out;
+        bf16_t* orow = w.out + (size_t)(row - a.q_begin) * a.ld_out + (quad & 1) * 16 + (quad >> 1) * 8;
 #pragma unroll
-            for (int dt = 0; dt < 8; ++dt) {
-                u32x2 pk;
-                pk[0] = pack_bf2(o[dt][g][0] * inv, o[dt][g][1] * inv);
-                pk[1] = pack_bf2(o[dt][g][2] * inv, o[dt][g][3] * inv);
-                *(u32x2*)(orow + dt * 16 + quad * 4) = pk;
+        for (int dp = 0; dp < 4; ++dp) {
+            uint32_t a0 = pack_bf2(o[2 * dp][g][0] * inv, o[2 * dp][g][1] * inv), a1 = pack_bf2(o[2 * dp][g][2] * inv, o[2 * dp][g][3] * inv);
+            uint32_t b0 = pack_bf2(o[2 * dp + 1][g][0] * inv, o[2 * dp + 1][g][1] * inv), b1 = pack_bf2(o[2 * dp + 1][g][2] * inv, o[2 * dp + 1][g][3] * inv);
+            {
+                const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+                const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+                a0 = r0[0]; b0 = r0[1]; a1 = r1[0]; b1 = r1[1];
             }
+            if (row < a.Lq_rows) *(u32x4*)(orow + dp * 32) = u32x4{a0, a1, b0, b1};
         }
     }
 }
-
 
 __global__ __launch_bounds__(512, 2) void attn16_kernel(AttnArgs a) {
     const int tid = threadIdx.x;

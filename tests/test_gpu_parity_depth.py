@@ -113,8 +113,9 @@ def test_each_op_within_1e3_on_identical_inputs():
         else:
             assert v_[0] < 1e-3, f"{name}: mean relative error {v_[0]:.3e} is above the north-star 1e-3"
     # attention: as close to exact arithmetic as the reference's own bf16 kernel (measured 1.0x), and within 1 bf16 ulp of it
-    assert out["attention_L2438_H32_vs_fp32"][0] <= 1.1 * out["attention_cpu_bf16_vs_fp32"][0]
-    assert out["attention_L2438_H32_vs_cpu_bf16"][0] < 3e-3
+    # measured (round 6, 16x16x32 kernel): ours-vs-fp32 2.259e-3 = 1.031 x the CPU bf16 kernel's 2.191e-3; vs the CPU kernel 2.163e-3
+    assert out["attention_L2438_H32_vs_fp32"][0] <= 1.06 * out["attention_cpu_bf16_vs_fp32"][0]
+    assert out["attention_L2438_H32_vs_cpu_bf16"][0] < 2.4e-3
 
 
 # ------------------------------------------------------------------------------------------------ (2)+(3) full depth
@@ -122,8 +123,9 @@ def test_each_op_within_1e3_on_identical_inputs():
 # mean rel err HIP-vs-oracle 4.5e-3 after block 0 growing to 2.77e-2 after block 31, while BOTH are 2.85e-2 from exact fp32
 # arithmetic (HIP 2.852e-2, reference bf16 2.854e-2); logits: mean |err| 0.0222 sigma, max 0.18 sigma, arg-max agreement
 # 94.5 % (text) / 93.3 % (image) HIP-vs-oracle — the reference's own bf16 path agrees with exact arithmetic on 93.0 % / 92.6 %.
-LIM = dict(stream_mean_rel_last=3.5e-2, text_logit_mean_abs_in_sigma=2.8e-2, image_logit_mean_abs_in_sigma=2.8e-2,
-           argmax_agree_min=0.90, envelope_ratio=1.05)
+# measured + 10 % (round 6): stream 2.77e-2; text / image logits 2.22e-2 sigma; HIP-vs-fp32 = 1.000 x oracle-vs-fp32
+LIM = dict(stream_mean_rel_last=3.1e-2, text_logit_mean_abs_in_sigma=2.45e-2, image_logit_mean_abs_in_sigma=2.45e-2,
+           argmax_agree_min=0.90, envelope_ratio=1.03)
 
 
 def _logit_report(name, got, ref, f32=None):
@@ -326,7 +328,7 @@ def test_full_depth_8b_forward_vs_oracle():
         assert row["text_logits"]["argmax_agreement"] >= LIM["argmax_agree_min"], name
         assert row["image_logits"]["argmax_agreement"] >= LIM["argmax_agree_min"], name
         if want_f32:  # hip_tp_vs_fp32 <= 1.1 x oracle_bf16_vs_fp32, on the stream and on the consumed logits
-            assert row["stream_vs_fp32"][0] <= 1.1 * row["oracle_bf16_stream_vs_fp32"][0], (name, row["stream_vs_fp32"])
+            assert row["stream_vs_fp32"][0] <= 1.06 * row["oracle_bf16_stream_vs_fp32"][0], (name, row["stream_vs_fp32"])   # measured 1.032-1.039
             for rep in (row["text_logits"], row["image_logits"]):
                 env = rep["envelope"]
                 assert env["hip_vs_fp32_mean_abs"] <= 1.1 * env["oracle_bf16_vs_fp32_mean_abs"], (name, env)
