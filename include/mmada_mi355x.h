@@ -356,6 +356,11 @@ int mmada_set_option(const char* name, int value);
 /* The tile configuration the GEMM planner picks for a plain [M, K] x [N, K]^T product (host arithmetic, no launch): 0..3 = the
  * 8-phase configurations in the order above, 1000 + BM = the 16-wave kernel, -1 = unsupported shape.  Honours "gemm_config". */
 int mmada_gemm_plan(int M, int N, int K);
+/* The attention kernel's launch plan (host arithmetic, no launch): workgroups per (batch, head) pair for `pairs` pairs of `groups`
+ * 16-row query groups each against `keys` keys — the smallest count with the least estimated time, rounds (of 256 workgroups) x
+ * (largest per-SIMD share x key tiles x 0.405 us + 5.7 us per round); a workgroup holds at most 24 groups.  L = 2438 with 32
+ * heads: 153 groups -> 8 workgroups per head, one round at batch 1. */
+int mmada_attention_plan(int pairs, int groups, int keys);
 
 /* ---- attainable-MFMA probe (bench.py's roofline.attainable_tflops; measurement only, no reference counterpart) -----
  * Runs `launches` launches of an MFMA-only kernel (v_mfma_f32_16x16x32_bf16 on register-resident operand fragments taken

@@ -74,6 +74,7 @@ SIGNATURES = {
     "mmada_set_option": (c_int, [C.c_char_p, c_int]),
     "mmada_gemm_swiglu_bt": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "mmada_gemm_plan": (c_int, [c_int, c_int, c_int]),
+    "mmada_attention_plan": (c_int, [c_int, c_int, c_int]),
     "mmada_probe_f2bf": (c_int, [c_void_p, c_void_p, C.c_int64, c_void_p]),
     "mmada_mfma_probe_bytes": (c_size_t, []),
     "mmada_mfma_probe": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

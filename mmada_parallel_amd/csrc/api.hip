@@ -324,6 +324,10 @@ int mmada_gemm_swiglu_bt(const void* A, const void* W, void* C, int M, int N, in
 }
 
 int mmada_gemm_plan(int M, int N, int K) { return gemm_plan_code(M, N, K); }
+int mmada_attention_plan(int pairs, int groups, int keys) {
+    if (pairs <= 0 || groups <= 0 || keys <= 0) return mm_fail("mmada_attention_plan: bad argument"), -1;
+    return attention_chunks(pairs, groups, keys);
+}
 
 int mmada_probe_f2bf(const float* in, uint16_t* out, int64_t n, void* stream) {
     if (!in || !out || n < 0) return mm_fail("mmada_probe_f2bf: bad argument");

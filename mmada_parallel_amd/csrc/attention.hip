@@ -308,16 +308,18 @@ __global__ __launch_bounds__(512, 2) void attn16_kernel(AttnArgs a) {
 
 }  // namespace
 
-// Workgroups per (batch, head) pair: the smallest count whose rounds x (largest SIMD share) is least.  A workgroup holds at
-// most 24 groups (8 waves x 3); one round is 256 workgroups.
-int attention_chunks(int pairs, int groups) {
+// Workgroups per (batch, head) pair: the smallest count with the least estimated time  rounds x (largest SIMD share x key tiles x
+// T + F): T = 0.405 us per group and key tile, F = 5.7 us of prologue + epilogue per round of 256 workgroups (measured:
+// profiles/r06_attention_time_vs_L.txt).  A workgroup holds at most 24 groups (8 waves x 3).
+int attention_chunks(int pairs, int groups, int keys) {
+    const double nkt = (keys + KB - 1) / KB;
     int best = 0;
-    long best_cost = 0;
+    double best_cost = 0;
     for (int c = (groups + 23) / 24; c <= groups; ++c) {
         const int n = (groups + c - 1) / c;
         const long rounds = ((long)pairs * c + 255) / 256;
-        const long cost = rounds * ((n + 3) / 4);
-        if (!best || cost < best_cost) { best = c; best_cost = cost; }
+        const double cost = rounds * (((n + 3) / 4) * nkt * 0.405 + 5.7);
+        if (!best || cost < best_cost - 1e-9) { best = c; best_cost = cost; }
         if (n == 1) break;
     }
     return best ? best : 1;
@@ -351,7 +353,7 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     a.plain_order = g_attn_form == 0;
     const int pairs = Hq * B;
     a.groups = (Lq_rows - q_begin + 15) / 16;
-    a.chunks = attention_chunks(pairs, a.groups);
+    a.chunks = attention_chunks(pairs, a.groups, L);
     a.xcd_pairs = (pairs % 8 == 0) ? pairs / 8 : 0;
     hipLaunchKernelGGL(attn16_kernel, dim3(pairs * a.chunks), dim3(512), ATT16_LDS, s, a);
     MM_CHECK_HIP(hipGetLastError());

@@ -81,7 +81,7 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
                      int Lq_rows, int Lkv, int out_row_stride_per_batch, int ld_out, hipStream_t s, int q_begin = 0,
                      int Lq_alloc = 0);
 
-int attention_chunks(int pairs, int groups);  // workgroups per (batch, head) pair (the launch plan; host arithmetic)
+int attention_chunks(int pairs, int groups, int keys);  // workgroups per (batch, head) pair (the launch plan; host arithmetic)
 void attention_force_form(int form);  // 0: every wave in the plain order, 1: late waves (default); tests compare the two
 
 // sampler.hip

@@ -147,8 +147,8 @@ class ReplayCpuRng:
         return torch.multinomial(probs2d.cpu(), 1, generator=generator).to(probs2d.device)
 
 
-# ---- measured parity numbers (tests/test_gpu_parity_depth.py, test_gpu_fullsize.py) -> gpurun_out/r05_parity.json (copied to profiles/ after a full suite run) ----
-PARITY_REPORT = os.path.join(ROOT, "gpurun_out", "r05_parity.json")
+# ---- measured parity numbers (tests/test_gpu_parity_depth.py, test_gpu_fullsize.py) -> gpurun_out/r06_parity.json (copied to profiles/ after a full suite run) ----
+PARITY_REPORT = os.path.join(ROOT, "gpurun_out", "r06_parity.json")
 
 
 def save_parity(section, payload):

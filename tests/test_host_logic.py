@@ -354,3 +354,33 @@ def test_gemm_planner_picks_the_measured_best_on_the_committed_sweep():
         points += 1
     assert points == 32
     assert lib.mmada_gemm_plan(2440, 4096, 100) == -1   # K is not a multiple of the K-tile
+
+
+def test_attention_plan():
+    """The launch plan of the attention kernel (csrc/attention.hip: attention_chunks through mmada_attention_plan, host arithmetic):
+    a (batch, head) pair's 16-row query groups are cut into the fewest workgroups with the least estimated time
+    rounds x (largest SIMD share x key tiles x 0.405 us + 5.7 us).  The property DESIGN §3.2 rests on: BASELINE configs[1]
+    (L = 2438 -> 153 groups, 32 heads) runs ONE round of 256 workgroups at batch 1 with at most 5 groups per SIMD, and B rounds
+    at batch B (configs[4]: 48 sequences)."""
+    from mmada_parallel_amd import abi
+
+    lib = abi.lib()
+
+    def cost(pairs, groups, keys, c):
+        n = -(-groups // c)
+        return -(-pairs * c // 256) * (-(-n // 4) * -(-keys // 64) * 0.405 + 5.7)
+
+    for B in (1, 2, 3, 16, 48):
+        c = lib.mmada_attention_plan(32 * B, 153, 2438)
+        assert c == 8, (B, c)                       # 8 workgroups per head: 19-20 groups each, 5 per SIMD
+        assert -(-153 // c) == 20 and -(-32 * B * c // 256) == B
+    assert lib.mmada_attention_plan(32, 104, 1654) in range(5, 9)     # configs[0]
+    for pairs, groups, keys in ((1, 1, 1), (4, 153, 2438), (8, 7, 100), (16, 21, 333), (24, 63, 1000), (32, 83, 1313), (96, 153, 2438),
+                                (64, 147, 2349), (32, 16, 2438)):
+        c = lib.mmada_attention_plan(pairs, groups, keys)
+        assert 1 <= c <= groups and -(-groups // c) <= 24, (pairs, groups, c)       # a workgroup holds at most 8 waves x 3 groups
+        lo = -(-groups // 24)
+        best = min(cost(pairs, groups, keys, k) for k in range(lo, groups + 1))
+        assert abs(cost(pairs, groups, keys, c) - best) < 1e-6, (pairs, groups, keys, c, best)
+        assert all(cost(pairs, groups, keys, k) > best + 1e-9 for k in range(lo, c)), "the smallest count that reaches it"
+    assert lib.mmada_attention_plan(0, 5, 64) == -1 and lib.mmada_attention_plan(3, 0, 64) == -1
