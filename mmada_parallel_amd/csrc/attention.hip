@@ -104,6 +104,8 @@ MM_DEVICE void attn16_wave(const AttnArgs& a, const Wave16& w) {
     auto pv = [&](int vbase) {  // O^T += V^T · P^T of the tile whose vT sits at LDS byte vbase
         if constexpr (NG > 0) {
             A8_SB();
+            if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+            if (a.prio == 2) __builtin_amdgcn_s_setprio(0);
             int va[2];
 #pragma unroll
             for (int k2 = 0; k2 < 2; ++k2) va[k2] = vro[k2] + vbase;
@@ -123,6 +125,8 @@ MM_DEVICE void attn16_wave(const AttnArgs& a, const Wave16& w) {
                 __builtin_amdgcn_sched_group_barrier(0x008, NG, 1);
                 if (n + 4 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
             }
+            if (a.prio == 1) __builtin_amdgcn_s_setprio(0);
+            if (a.prio == 2) __builtin_amdgcn_s_setprio(1);
             A8_SB();
         }
     };
@@ -130,6 +134,8 @@ MM_DEVICE void attn16_wave(const AttnArgs& a, const Wave16& w) {
     auto scores = [&](int kt, int kbase) {  // S(kt) and its soft-max -> pb
         if constexpr (NG > 0) {
             A8_SB();
+            if (a.prio == 1) __builtin_amdgcn_s_setprio(1);
+            if (a.prio == 2) __builtin_amdgcn_s_setprio(0);
             int ka[4];
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) ka[ks] = kro[ks] + kbase;
@@ -154,6 +160,8 @@ MM_DEVICE void attn16_wave(const AttnArgs& a, const Wave16& w) {
                 __builtin_amdgcn_sched_group_barrier(0x008, NG, 0);
                 if (n + 4 < 16) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
+            if (a.prio == 1) __builtin_amdgcn_s_setprio(0);
+            if (a.prio == 2) __builtin_amdgcn_s_setprio(1);
             A8_SB();
             // keys past L (only in the last tile) get -inf; select, not arithmetic, so garbage K rows cannot leak NaN
             if (kt * KB + KB > a.L) {
@@ -325,6 +333,9 @@ int attention_chunks(int pairs, int groups, int keys) {
     return best ? best : 1;
 }
 
+static int g_attn_prio = 1;   // 1 (default): s_setprio 1 around the matrix blocks (+1.2 %: the partner's soft-max fills the gaps instead of
+                              // winning the arbitration); 0: none; 2: around the soft-max instead (measurement hook: attention_set_prio)
+void attention_set_prio(int v) { g_attn_prio = v; }
 static int g_attn_form = -1;  // -1: read MMADA_ATTN_FORM once
 void attention_force_form(int form) { g_attn_form = form; }  // measurement / test hook; -1: back to MMADA_ATTN_FORM / default
 
@@ -351,6 +362,7 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     if (Lq_rows > a.Lq_alloc) return mm_fail("attention: Lq_rows=%d exceeds the q allocation %d", Lq_rows, a.Lq_alloc);
     a.scale_log2e = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
     a.plain_order = g_attn_form == 0;
+    a.prio = g_attn_prio;
     const int pairs = Hq * B;
     a.groups = (Lq_rows - q_begin + 15) / 16;
     a.chunks = attention_chunks(pairs, a.groups, L);
