@@ -14,11 +14,11 @@
  *   - all work is enqueued on the `stream` argument (a hipStream_t passed as void*); no hidden host syncs
  *     (mmada_bind_* and mmada_create allocate and are not graph-capturable; the forward / select calls are).
  *   - one handle per (process, device); a handle is used from one host thread at a time.
- *   - process-global state: the launchers set kernel attributes (dynamic LDS size) once per process behind unsynchronised
- *     function-local statics, and keep one zero row per device index (< 16).  This is correct for the supported model —
- *     ONE process per GPU, launches from one host thread — and NOT for a host that launches from several threads at once
- *     or drives different devices concurrently from one process before each kernel has been launched once on a single
- *     thread (call every entry point once during start-up, as mmada_graph_* requires anyway).
+ *   - process-global state: kernel attributes (dynamic LDS size) and the per-device constants of the GEMM launchers (zero rows,
+ *     SiLU table: mmada_create builds them) sit behind per-device atomic latches that are set only after the call succeeded —
+ *     two host threads at worst repeat an idempotent call; the measurement switches of mmada_set_option are process-global
+ *     atomics read once per launch.  The supported model stays ONE process per GPU with launches from one host thread per
+ *     handle; several handles of one process (the ranks of a test group) may be driven from different threads.
  */
 #ifndef MMADA_MI355X_H
 #define MMADA_MI355X_H

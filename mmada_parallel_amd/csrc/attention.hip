@@ -333,10 +333,10 @@ int attention_chunks(int pairs, int groups, int keys) {
     return best ? best : 1;
 }
 
-static int g_attn_prio = 1;   // 1 (default): s_setprio 1 around the matrix blocks (+1.2 %: the partner's soft-max fills the gaps instead of
+static std::atomic<int> g_attn_prio{1};   // 1 (default): s_setprio 1 around the matrix blocks (+1.2 %: the partner's soft-max fills the gaps instead of
                               // winning the arbitration); 0: none; 2: around the soft-max instead (measurement hook: attention_set_prio)
 void attention_set_prio(int v) { g_attn_prio = v; }
-static int g_attn_form = -1;  // -1: read MMADA_ATTN_FORM once
+static std::atomic<int> g_attn_form{-1};  // -1: read MMADA_ATTN_FORM once
 void attention_force_form(int form) { g_attn_form = form; }  // measurement / test hook; -1: back to MMADA_ATTN_FORM / default
 
 // form 1 (default): waves 4-7 run LATE (P·V one interval behind); form 0: every wave in the plain order — the same arithmetic
@@ -347,11 +347,13 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     if (Lkv % 64 || Lkv < L) return mm_fail("attention: Lkv=%d must be a multiple of 64 and >= L=%d", Lkv, L);
     if (Hq % Hkv) return mm_fail("attention: n_heads %% n_kv_heads != 0");
     if (q_begin < 0 || (q_begin & 31) || q_begin >= Lq_rows) return mm_fail("attention: bad q_begin=%d", q_begin);
-    if (g_attn_form < 0) {
+    int form = g_attn_form.load(std::memory_order_relaxed);
+    if (form < 0) {
         const char* e = getenv("MMADA_ATTN_FORM");
-        g_attn_form = e ? atoi(e) : 1;
+        form = e ? atoi(e) : 1;
+        g_attn_form.store(form, std::memory_order_relaxed);
     }
-    if (g_attn_form != 0 && g_attn_form != 1) return mm_fail("attention: form %d does not exist (0: plain order, 1: late waves)", g_attn_form);
+    if (form != 0 && form != 1) return mm_fail("attention: form %d does not exist (0: plain order, 1: late waves)", form);
     static MmOncePerDevice attr_set;
     MM_ONCE_PER_DEVICE(attr_set, MM_CHECK_HIP(hipFuncSetAttribute((const void*)attn16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ATT16_LDS)));
     AttnArgs a{};
@@ -361,8 +363,8 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
     a.Lq_alloc = Lq_alloc > 0 ? Lq_alloc : Lkv;
     if (Lq_rows > a.Lq_alloc) return mm_fail("attention: Lq_rows=%d exceeds the q allocation %d", Lq_rows, a.Lq_alloc);
     a.scale_log2e = 0.08838834764831845f * 1.4426950408889634f;  // 1/sqrt(128) * log2(e)
-    a.plain_order = g_attn_form == 0;
-    a.prio = g_attn_prio;
+    a.plain_order = form == 0;
+    a.prio = g_attn_prio.load(std::memory_order_relaxed);
     const int pairs = Hq * B;
     a.groups = (Lq_rows - q_begin + 15) / 16;
     a.chunks = attention_chunks(pairs, a.groups, L);

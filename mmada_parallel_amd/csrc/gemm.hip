@@ -187,7 +187,7 @@ constexpr float A8 = 0.00483f, D0 = 2.7f, D1 = 0.025f;
 constexpr float H8[GEMM8_NCFG] = {1.0f, 1.0f, 1.08f, 1.08f};
 struct Plan { bool p8; int code; };  // code: GEMM8_* configuration or the 16-wave kernel's BM
 
-int g_force = -2;  // -2: read MMADA_GEMM_CFG once; -1: automatic; else gemm_force_config's code
+std::atomic<int> g_force{-2};  // -2: read MMADA_GEMM_CFG once; -1: automatic; else gemm_force_config's code
 
 Plan plan(const GemmArgs& g) {
     if (g_force == -2) {

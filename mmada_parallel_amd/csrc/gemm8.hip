@@ -367,7 +367,7 @@ struct Gemm8 {
 };
 
 // mmada_set_option("gemm_short_tiles", 0) / MMADA_GEMM_SHORT_TILES=0: every row tile full height (the round-3 kernel; A/B timing)
-int g_short_tiles = -1;
+std::atomic<int> g_short_tiles{-1};
 bool short_tiles_on() {
     if (g_short_tiles < 0) {
         const char* e = getenv("MMADA_GEMM_SHORT_TILES");
@@ -376,7 +376,7 @@ bool short_tiles_on() {
     return g_short_tiles != 0;
 }
 
-int g_tile_order = -1;  // -1: read MMADA_GEMM_TILE_ORDER once; 0: per-tile default (launch_cfg8); GM * 100 + GN (GM = 99: all row tiles)
+std::atomic<int> g_tile_order{-1};  // -1: read MMADA_GEMM_TILE_ORDER once; 0: per-tile default (launch_cfg8); GM * 100 + GN (GM = 99: all row tiles)
 
 template <int EPI, class G>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs g) {

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(4 * 64, 2) void mfma_probe16w4_kernel(const bf16_t*
 
 // data: >= 64 * 8 * 16 * 64 * 16 bytes (8 MiB) of bf16 values the caller filled (random: never zeros — see above).
 // Runs `launches` back-to-back launches of `iters` iterations on `stream` and returns the achieved dense TFLOP/s.
-static int g_probe_variant = 0;
+static std::atomic<int> g_probe_variant{0};
 void mfma_probe_set_variant(int v) { g_probe_variant = v & 3; }
 
 int launch_mfma_probe(const bf16_t* data, float* sink, int iters, int launches, hipStream_t s, double* tflops_out, double* ms_out) {

@@ -43,7 +43,7 @@
 
 #include "handle.h"
 
-int g_allow_single_rank = 0;   // mmada_set_option("tp_allow_single_rank", 1): test switch, see mmada_comm_create
+std::atomic<int> g_allow_single_rank{0};   // mmada_set_option("tp_allow_single_rank", 1): test switch, see mmada_comm_create
 void tp_allow_single_rank(int on) { g_allow_single_rank = on != 0; }
 
 namespace {
