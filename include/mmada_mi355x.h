@@ -341,9 +341,6 @@ int mmada_profile_end(mmada_handle* h, int32_t* count_out /*[5]*/, double* ms_ou
  *                    (320x256, 256x256, 160x256, 320x128); 1000 + BM the 16-wave kernel with that row-tile height
  *   "attention_form" -1 automatic (default: MMADA_ATTN_FORM or 1); 0 every wave of a workgroup in the plain order
  *                    { S, soft-max, P·V }; 1 waves 4-7 accumulate P·V one key tile late (bit-identical output)
- *   "attention_prio" 1 (default): a wave raises its priority (s_setprio 1) for its matrix blocks, so that its SIMD partner's soft-max
- *                    fills the MFMA gaps instead of winning the arbitration; 0: no priority changes; 2: around the soft-max instead
- *                    (same bits, measurement hook)
  *   "gemm_silu_lut"  1 (default): the 8-phase SwiGLU epilogue reads SiLU of the bf16 gate value from a 10-KiB table in the LDS (filled on
  *                    the device by the function it replaces; untabulated values are evaluated); 0: always evaluate
  *   "gemm_short_tiles" 1 (default): the 320-row configurations use a row-tile pitch of 304 when ntm - 1 tiles of 304 rows and

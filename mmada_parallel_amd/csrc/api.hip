@@ -310,7 +310,6 @@ int mmada_set_option(const char* name, int value) {
     if (!strcmp(name, "gemm_short_tiles")) { gemm8_set_short_tiles(value); return 0; }
     if (!strcmp(name, "gemm_tile_order")) { gemm8_set_tile_order(value); return 0; }
     if (!strcmp(name, "attention_form")) { attention_force_form(value); return 0; }
-    if (!strcmp(name, "attention_prio")) { attention_set_prio(value); return 0; }
     if (!strcmp(name, "probe_variant")) { mfma_probe_set_variant(value); return 0; }
     if (!strcmp(name, "tp_allow_single_rank")) { tp_allow_single_rank(value); return 0; }
     return mm_fail("mmada_set_option: unknown option '%s'", name);

@@ -27,7 +27,6 @@ struct AttnArgs {
     int xcd_pairs;      // XCD-aware grid: (batch, head) pairs per XCD (0: pair-major grid)
     int groups, chunks; // 16-row query groups per (batch, head) pair and workgroups the pair is cut into
     int plain_order;    // 1: no late waves (attention form 0)
-    int prio;           // 1: s_setprio 1 around the matrix blocks; 2: around the soft-max (tuning)
 };
 
 // The kernel owns its whole LDS allocation and has no static __shared__ object: the dynamic segment starts at LDS address 0

@@ -82,7 +82,6 @@ int launch_attention(const bf16_t* q, const bf16_t* k, const bf16_t* vT, bf16_t*
                      int Lq_alloc = 0);
 
 int attention_chunks(int pairs, int groups, int keys);  // workgroups per (batch, head) pair (the launch plan; host arithmetic)
-void attention_set_prio(int v);
 void attention_force_form(int form);  // 0: every wave in the plain order, 1: late waves (default); tests compare the two
 
 // sampler.hip

@@ -251,6 +251,32 @@ def test_attention_forms_are_bit_identical(handle, B, H, Hkv, L):
     assert torch.equal(outs[0], outs[1]), f"{int((outs[0] != outs[1]).sum())} elements differ"
 
 
+@pytest.mark.parametrize("H,L", [(8, 1000), (32, 333), (16, 2438)])
+def test_attention_is_invariant_to_its_launch_plan(handle, H, L):
+    """A query row's arithmetic does not depend on which wave, workgroup or round carries its 16-row group (csrc/attention.hip):
+    the launch plan (mmada_attention_plan: workgroups per head, hence groups per wave) changes with the number of (batch, head)
+    pairs, so the same sequence inside batches of 1, 2 and 3 runs under different plans — and must give the same bits."""
+    torch.manual_seed(77 + L)
+    q = torch.randn(3, H, L, 128).to(torch.bfloat16).to(DEV)
+    k = torch.randn(3, H, L, 128).to(torch.bfloat16).to(DEV)
+    v = torch.randn(3, H, L, 128).to(torch.bfloat16).to(DEV)
+    k[:, 0, L // 3] *= 5.0   # some rows take the deferred-rescale branch
+    lib = abi.lib()
+    groups = (L + 15) // 16
+    plans = {B: lib.mmada_attention_plan(B * H, groups, L) for B in (1, 2, 3)}
+    outs = {}
+    for B in (1, 2, 3):
+        out = torch.full((B, L, H * 128), float("nan"), dtype=torch.bfloat16, device=DEV)
+        qb, kb, vb = (t[:B].contiguous() for t in (q, k, v))
+        abi.check(lib.mmada_sdpa(handle, qb.data_ptr(), kb.data_ptr(), vb.data_ptr(), out.data_ptr(), B, H, H, L, st()), "sdpa")
+        torch.cuda.synchronize()
+        outs[B] = out
+    assert torch.isfinite(outs[3].float()).all()
+    assert torch.equal(outs[1][0], outs[3][0]) and torch.equal(outs[2], outs[3][:2]), plans
+    if (H, L) == (8, 1000):
+        assert len(set(plans.values())) > 1, plans   # the case really exercises different plans
+
+
 @pytest.mark.parametrize("B,H,Hkv,L", [(1, 2, 2, 70), (2, 2, 1, 333), (1, 4, 4, 1000), (1, 2, 2, 64), (1, 1, 1, 1),
                                        (1, 2, 2, 2438)])
 def test_sdpa(handle, B, H, Hkv, L):

@@ -4,7 +4,7 @@ attention forms at the 8B shapes (kernel times come from rocprofv3 --kernel-trac
 figure printed here is the whole mmada_sdpa call incl. its three layout kernels).
 
     python tools/attn16_dev.py --check            # shapes incl. partial groups / tiles, GQA, forced rescale
-    python tools/attn16_dev.py --time --batch 1   # forms "1,0" = late waves (default), plain order; "1:0" = form 1 without s_setprio
+    python tools/attn16_dev.py --time --batch 1   # forms "1,0" = late waves (default), plain order
 (Round 6 used it with extra kernel variants — half-step pipeline, shadowed exponentials — that were measured and removed:
 profiles/HISTORY.md.)
 """
@@ -89,7 +89,6 @@ def timing(lib, h, st, args):
     for _ in range(args.rounds):
         for f in forms:
             abi.check(lib.mmada_set_option(b"attention_form", f[0]), "opt")
-            lib.mmada_set_option(b"attention_prio", f[1])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             run(args.iters)
@@ -121,7 +120,6 @@ def main():
     if args.time:
         timing(lib, h, st, args)
     lib.mmada_set_option(b"attention_form", -1)
-    lib.mmada_set_option(b"attention_prio", 1)
 
 
 if __name__ == "__main__":
