@@ -244,13 +244,14 @@ MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[T
     const int mrow0 = m0 + wm * TM + lrow;
     const int wcol0 = n0 + wn * TN;  // first column of this wave (wave-uniform)
 
-    if constexpr (EPI == EPI_STORE || EPI == EPI_RESID) {
+    if constexpr ((EPI == EPI_STORE || EPI == EPI_RESID) && FM <= 5) {
         // The residual (the other buffer of the x / y ping-pong: never aliases C) is read for up to FIVE fragment rows at a time, all
         // their 16-byte loads in flight together; hipcc otherwise orders every fragment row's loads behind the previous row's stores
         // with `s_waitcnt vmcnt(0)` (it cannot prove that resid and C do not alias, and vmcnt counts stores): FM serial round trips
-        // in the tail of every tile, which a one-round launch (attn_out, down at batch 1) exposes in full.  (Five rows = 40
-        // registers: the 320-row tile, FM = 10, has no room for all ten and takes two batches.)
-        constexpr int RB = FM <= 5 ? FM : (FM + 1) / 2;
+        // in the tail of every tile, which a one-round launch (attn_out, down at batch 1) exposes in full.  (The 320-row tiles, FM = 10, keep the row-by-row form below:
+        // two batches of five made their short-K tensor-parallel launches — where the epilogue is half of a tile's time — 9 % slower,
+        // and their launches at TP = 1 have two or more rounds, whose tails overlap other workgroups' main loops anyway.)
+        constexpr int RB = FM;
 #pragma unroll
         for (int mb = 0; mb < FM; mb += RB) {
             u32x4 rres[EPI == EPI_RESID ? RB : 1][EPI == EPI_RESID ? FN / 2 : 1];
@@ -271,7 +272,9 @@ MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[T
 #pragma unroll
                     for (int ni = 0; ni < FN; ni += 2) {   // dead rows / columns read a valid address (row m_lim - 1, column clamped) and are not stored
                         const int n = min(wcol0 + ni * 16 + run8_col(lq), g.N - 8);
-                        rres[mj][ni / 2] = *(const u32x4*)(g.resid + rrow * g.ldr + n);
+                        // wave-uniform branch: under tensor parallelism only the owner rank of a fragment row adds (and reads) the residual
+                        if (radd[mj]) rres[mj][ni / 2] = *(const u32x4*)(g.resid + rrow * g.ldr + n);
+                        else rres[mj][ni / 2] = u32x4{0u, 0u, 0u, 0u};
                     }
                 }
                 // ONE place where the loads are waited for: behind this statement the values are the asm's, not the loads', so hipcc
@@ -310,6 +313,40 @@ MM_DEVICE void gemm_epilogue_t(const GemmArgs& g, int m0, int n0, f32x4 (&acc)[T
                     }
                     *(u32x4*)(g.C + (size_t)m * g.ldc + n) = o;
                 }
+            }
+        }
+    } else if constexpr (EPI == EPI_STORE || EPI == EPI_RESID) {
+#pragma unroll
+        for (int mi = 0; mi < FM; ++mi) {
+            const int m = mrow0 + mi * 16;
+            const bool live = m < m_lim;  // the swaps below are wave-wide: every lane takes part, dead rows only skip memory
+            // wave-uniform: the 16 rows of a fragment share one residual owner
+            const bool add = EPI == EPI_RESID && (g.resid_mod == 1 || ((m >> 4) % g.resid_mod) == g.resid_rank);
+            size_t rrow = (size_t)m;  // residual row (compact -> full layout when a row window is active)
+            if (EPI == EPI_RESID && g.rwin) {
+                const int bb = m / g.rwin;
+                rrow = (size_t)bb * g.rlp + g.rbeg + (m - bb * g.rwin);
+            }
+#pragma unroll
+            for (int ni = 0; ni < FN; ni += 2) {
+                // every nn.Linear output is rounded to bf16 first (exactly representable afterwards: the exchange is lossless)
+                uint32_t a0 = pack_bf2(acc[mi][ni][0], acc[mi][ni][1]), a1 = pack_bf2(acc[mi][ni][2], acc[mi][ni][3]);
+                uint32_t b0 = pack_bf2(acc[mi][ni + 1][0], acc[mi][ni + 1][1]), b1 = pack_bf2(acc[mi][ni + 1][2], acc[mi][ni + 1][3]);
+                swap_halves16(a0, b0);
+                swap_halves16(a1, b1);
+                const int n = wcol0 + ni * 16 + run8_col(lq);
+                if (!live || n >= g.N) continue;  // N is a multiple of 8 here: a lane's eight columns are all inside or all outside
+                u32x4 o{a0, a1, b0, b1};
+                if constexpr (EPI == EPI_RESID) {
+                    if (add) {
+                        const u32x4 rv = *(const u32x4*)(g.resid + rrow * g.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            o[e] = pack_bf2(__uint_as_float(rv[e] << 16) + __uint_as_float(o[e] << 16),
+                                            __uint_as_float(rv[e] & 0xffff0000u) + __uint_as_float(o[e] & 0xffff0000u));
+                    }
+                }
+                *(u32x4*)(g.C + (size_t)m * g.ldc + n) = o;
             }
         }
     } else if constexpr (EPI == EPI_SWIGLU) {
