@@ -60,7 +60,9 @@ def check(lib, h, st):
         same = torch.equal(res[0], res[1])
         nan = bool(torch.isnan(res[1]).any())
         worst = max(worst, e_new)
-        print(f"B={B} H={H}/{Hkv} L={L} spike={spike}: max|err| vs fp32 {e_new:.3e}  form 0 == form 1 bits {same}  nan {nan}", flush=True)
+        bits = res[1].to(torch.bfloat16).view(torch.int16).to(torch.int64)
+        digest = int((bits * torch.arange(1, bits.numel() + 1, device=bits.device).view(bits.shape) % 1000003).sum().item())
+        print(f"B={B} H={H}/{Hkv} L={L} spike={spike}: max|err| vs fp32 {e_new:.3e}  form 0 == form 1 bits {same}  nan {nan}  digest {digest}", flush=True)
     print("worst new", worst)
 
 
