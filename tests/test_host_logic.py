@@ -321,7 +321,7 @@ def test_bench_self_launch_relays_the_line_and_the_exit_code(tmp_path):
 
 def test_gemm_planner_picks_the_measured_best_on_the_committed_sweep():
     """csrc/gemm.hip prices every tile configuration with a fitted cost model.  The committed sweep (profiles/
-    r05_gemm8_sweep_final.txt, taken with the -DMMADA_TUNE build of the FINAL round-5 product sources — tools/build_tune.py, no fork
+    r06_gemm8_sweep_final.txt, taken with the -DMMADA_TUNE build of the FINAL round-6 product sources — tools/build_tune.py, no fork
     of any kernel: 32 (shape, M) points of the TP = 1 / 2 / 4 / 8 projection shapes, all 8-phase configurations and two 16-wave ones
     measured side by side) is the evidence for its constants: on every point the planner's pick (mmada_gemm_plan — host arithmetic,
     no GPU) must be a configuration whose MEASURED rate is within 3 % of the best measured one."""
@@ -337,7 +337,7 @@ def test_gemm_planner_picks_the_measured_best_on_the_committed_sweep():
     lib = abi.lib()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cols, points = None, 0
-    for ln in open(os.path.join(root, "profiles", "r05_gemm8_sweep_final.txt")):
+    for ln in open(os.path.join(root, "profiles", "r06_gemm8_sweep_final.txt")):
         p = ln.split()
         if not p or ln.startswith("#"):
             continue
